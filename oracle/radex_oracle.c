@@ -1,0 +1,726 @@
+/*
+ * radex_oracle.c -- CPU restatement of the reference hot path.
+ * TEST INFRASTRUCTURE ONLY (see radex_oracle.h).  Plain C, IEEE double.
+ *
+ * Every function cites the reference location it follows:
+ *   [REF file:line]  = /root/reference/<file>:<line>
+ *   [BIN 0xADDR]     = address inside /root/reference/emcee/pyradex/radex/radex.so
+ *                      (x86-64 Mach-O), arithmetic per SURVEY.md Appendix A.
+ * Compile with -ffp-contract=off so no FMA contraction changes the rounding
+ * relative to the reference binary (which contains no FMA instructions).
+ */
+#include "radex_oracle.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- constants, Appendix A.0 (binary literals; float32-promoted where the
+ *      Fortran source lacked a d0 exponent) -------------------------------- */
+static const double FK     = 1.4387809925261357;      /* [BIN 0x26bc8] hc/k   */
+static const double THC    = 3.972907393443411e-16;   /* [BIN 0x26bd8] 2hc    */
+static const double FGAUS  = 26.753802360251857;      /* [BIN 0x26c10]        */
+static const double MINPOP = 1e-20;                   /* [BIN 0x26c20]        */
+static const double CCRIT  = 9.999999974752427e-07;   /* [BIN 0x26c28] 1e-6f  */
+static const double RELAX_NEW = 0.30000001192092896;  /* [BIN 0x26c30] 0.3f   */
+static const double RELAX_OLD = 0.699999988079071;    /* [BIN 0x26c38] 0.7f   */
+static const double EXPGUARD = 160.0;                 /* [BIN 0x26bd0]        */
+static const double SEED_D = 1e-30;                   /* [BIN 0x26bb8]        */
+static const double SEED_F = 1.0000000031710769e-30;  /* [BIN 0x26c40] 1e-30f */
+static const double THICK_D = 0.01;                   /* [BIN 0x26c18]        */
+static const double THICK_F = 0.009999999776482582;   /* [BIN 0x26b78] 0.01f  */
+static const double FAT     = 1e5;                    /* [BIN 0x26bc0]        */
+/* Python-side constants, astropy CODATA-2018 [REF emcee/pyradex/core.py:981-984] */
+static const double THC_PY = 3.9728917142978573e-16;
+static const double FK_PY  = 1.4387768775039338;
+
+static void set_err(char *err, size_t n, const char *msg)
+{
+    if (err && n) { strncpy(err, msg, n - 1); err[n - 1] = 0; }
+}
+
+/* ======================================================================== */
+/* readdata_, file-format half [BIN 0x1cf90-0x1e338]; LAMDA layout as in    */
+/* SURVEY App. A.2.  Records are read strictly in file order, comment lines  */
+/* are consumed positionally exactly as RADEX does (it never looks at '!').  */
+/* ======================================================================== */
+static char *rd_line(FILE *f, char *buf, int n)
+{
+    if (!fgets(buf, n, f)) return NULL;
+    return buf;
+}
+
+/* Fortran list-directed reals accept D exponents */
+static double rd_real(char **pp, int *ok)
+{
+    char *p = *pp, tmp[64];
+    while (*p && (isspace((unsigned char)*p) || *p == ',')) p++;
+    int k = 0;
+    while (*p && !isspace((unsigned char)*p) && *p != ',' && k < 63) {
+        char c = *p++;
+        tmp[k++] = (c == 'd' || c == 'D') ? 'e' : c;
+    }
+    tmp[k] = 0;
+    *pp = p;
+    if (!k) { *ok = 0; return 0.0; }
+    char *end;
+    double v = strtod(tmp, &end);
+    if (*end) *ok = 0;
+    return v;
+}
+
+rxo_mol *rxo_mol_load(const char *path, char *err, size_t errlen)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) { set_err(err, errlen, "cannot open molecular data file"); return NULL; }
+    rxo_mol *m = (rxo_mol *)calloc(1, sizeof *m);
+    enum { LB = 1 << 16 };
+    char *buf = (char *)malloc(LB);
+    char *p; int ok = 1;
+#define NEXT() do { if (!rd_line(f, buf, LB)) { ok = 0; goto fail; } p = buf; } while (0)
+    NEXT();            /* !MOLECULE */
+    NEXT();            /* name */
+    NEXT();            /* !MOLECULAR WEIGHT */
+    NEXT(); m->amass = rd_real(&p, &ok);
+    NEXT();            /* !NUMBER OF ENERGY LEVELS */
+    NEXT(); m->nlev = (int)rd_real(&p, &ok);
+    if (!ok || m->nlev < 2 || m->nlev > 2999) { ok = 0; goto fail; }
+    m->eterm = (double *)calloc(m->nlev, sizeof(double));
+    m->gstat = (double *)calloc(m->nlev, sizeof(double));
+    NEXT();            /* !LEVEL + ... */
+    for (int i = 0; i < m->nlev; i++) {
+        NEXT(); (void)rd_real(&p, &ok);
+        m->eterm[i] = rd_real(&p, &ok);
+        m->gstat[i] = rd_real(&p, &ok);
+    }
+    NEXT();            /* !NUMBER OF RADIATIVE TRANSITIONS */
+    NEXT(); m->nline = (int)rd_real(&p, &ok);
+    if (!ok || m->nline < 1 || m->nline > 99999) { ok = 0; goto fail; }
+    m->iupp = (int *)calloc(m->nline, sizeof(int));
+    m->ilow = (int *)calloc(m->nline, sizeof(int));
+    m->aeinst = (double *)calloc(m->nline, sizeof(double));
+    m->spfreq = (double *)calloc(m->nline, sizeof(double));
+    m->eup = (double *)calloc(m->nline, sizeof(double));
+    m->xnu = (double *)calloc(m->nline, sizeof(double));
+    NEXT();            /* !TRANS + ... */
+    for (int l = 0; l < m->nline; l++) {
+        NEXT(); (void)rd_real(&p, &ok);
+        m->iupp[l] = (int)rd_real(&p, &ok);
+        m->ilow[l] = (int)rd_real(&p, &ok);
+        m->aeinst[l] = rd_real(&p, &ok);
+        m->spfreq[l] = rd_real(&p, &ok);
+        m->eup[l] = rd_real(&p, &ok);
+        if (!ok || m->iupp[l] < 1 || m->iupp[l] > m->nlev ||
+            m->ilow[l] < 1 || m->ilow[l] > m->nlev) { ok = 0; goto fail; }
+        /* xnu = energy difference, NOT the listed frequency [BIN 0x1d735-0x1d745] */
+        m->xnu[l] = m->eterm[m->iupp[l] - 1] - m->eterm[m->ilow[l] - 1];
+        if (m->xnu[l] < 1e-30) { ok = 0; goto fail; } /* "illegal line frequency" */
+    }
+    NEXT();            /* !NUMBER OF COLL PARTNERS */
+    NEXT(); m->npart = (int)rd_real(&p, &ok);
+    if (!ok || m->npart < 1 || m->npart > RXO_MAXPART) { ok = 0; goto fail; }
+    for (int ip = 0; ip < m->npart; ip++) {
+        NEXT();        /* !COLLISIONS BETWEEN */
+        NEXT(); m->part_id[ip] = (int)rd_real(&p, &ok);   /* first integer on the line */
+        if (!ok || m->part_id[ip] < 1 || m->part_id[ip] > RXO_MAXPART) { ok = 0; goto fail; }
+        NEXT();        /* !NUMBER OF COLL TRANS */
+        NEXT(); m->ncoll[ip] = (int)rd_real(&p, &ok);
+        NEXT();        /* !NUMBER OF COLL TEMPS */
+        NEXT(); m->ntemp[ip] = (int)rd_real(&p, &ok);
+        if (!ok || m->ncoll[ip] < 1 || m->ntemp[ip] < 1) { ok = 0; goto fail; }
+        m->temp[ip] = (double *)calloc(m->ntemp[ip], sizeof(double));
+        m->lcu[ip] = (int *)calloc(m->ncoll[ip], sizeof(int));
+        m->lcl[ip] = (int *)calloc(m->ncoll[ip], sizeof(int));
+        m->coll[ip] = (double *)calloc((size_t)m->ncoll[ip] * m->ntemp[ip], sizeof(double));
+        NEXT();        /* !COLL TEMPS */
+        NEXT();
+        for (int t = 0; t < m->ntemp[ip]; t++) m->temp[ip][t] = rd_real(&p, &ok);
+        NEXT();        /* !TRANS + UP + LOW + COLLRATES */
+        for (int c = 0; c < m->ncoll[ip]; c++) {
+            NEXT(); (void)rd_real(&p, &ok);
+            m->lcu[ip][c] = (int)rd_real(&p, &ok);
+            m->lcl[ip][c] = (int)rd_real(&p, &ok);
+            for (int t = 0; t < m->ntemp[ip]; t++)
+                m->coll[ip][(size_t)c * m->ntemp[ip] + t] = rd_real(&p, &ok);
+            if (!ok || m->lcu[ip][c] < 1 || m->lcu[ip][c] > m->nlev ||
+                m->lcl[ip][c] < 1 || m->lcl[ip][c] > m->nlev) { ok = 0; goto fail; }
+        }
+    }
+#undef NEXT
+    free(buf); fclose(f);
+    return m;
+fail:
+    free(buf); fclose(f);
+    rxo_mol_free(m);
+    set_err(err, errlen, "malformed LAMDA file");
+    return NULL;
+}
+
+void rxo_mol_free(rxo_mol *m)
+{
+    if (!m) return;
+    free(m->eterm); free(m->gstat); free(m->iupp); free(m->ilow);
+    free(m->aeinst); free(m->spfreq); free(m->eup); free(m->xnu);
+    for (int i = 0; i < RXO_MAXPART; i++) {
+        free(m->temp[i]); free(m->lcu[i]); free(m->lcl[i]); free(m->coll[i]);
+    }
+    free(m);
+}
+
+rxo_state *rxo_state_new(const rxo_mol *m, int method, double deltav_kms)
+{
+    rxo_state *s = (rxo_state *)calloc(1, sizeof *s);
+    int n = m->nlev, L = m->nline;
+    s->mol = m; s->method = method;
+    /* core.py:447-454: deltav km/s -> cm/s */
+    s->deltav = deltav_kms * 1e5;
+    s->crate = (double *)calloc((size_t)n * n, sizeof(double));
+    s->ctot = (double *)calloc(n, sizeof(double));
+    s->xpop = (double *)calloc(n, sizeof(double));
+    s->xpopold = (double *)calloc(n, sizeof(double));
+    s->tex = (double *)calloc(L, sizeof(double));
+    s->taul = (double *)calloc(L, sizeof(double));
+    s->backi = (double *)calloc(L, sizeof(double));
+    s->totalb = (double *)calloc(L, sizeof(double));
+    s->trj = (double *)calloc(L, sizeof(double));
+    s->yrate = (double *)calloc((size_t)n * n, sizeof(double));
+    s->rhs = (double *)calloc(n + 1, sizeof(double));
+    s->lu = (double *)calloc((size_t)n * n, sizeof(double));
+    s->ipvt = (int *)calloc(n, sizeof(int));
+    return s;
+}
+
+void rxo_state_free(rxo_state *s)
+{
+    if (!s) return;
+    free(s->crate); free(s->ctot); free(s->xpop); free(s->xpopold);
+    free(s->tex); free(s->taul); free(s->backi); free(s->totalb); free(s->trj);
+    free(s->yrate); free(s->rhs); free(s->lu); free(s->ipvt);
+    free(s);
+}
+
+/* ======================================================================== */
+/* readdata_, arithmetic half [BIN 0x1e338-0x1fd0a]:            */
+/*  - totdens = sum(density)                                  [BIN 0x1f390]  */
+/*  - per partner with density>0: bracket tkin, LINEAR interpolation of the  */
+/*    downward rates, crate(up,low) += density(id)*colld                     */
+/*  - detailed balance over ALL level pairs with eterm(iup)-eterm(ilo) > 0   */
+/*    [BIN 0x1f3dd-0x1fd0a]: e=(ediff*fk)/tkin; e>=160 -> 0 else              */
+/*    crate(ilo,iup) = (exp(-e)*(g(iup)/g(ilo)))*crate(iup,ilo)               */
+/*  - ctot(i) = sum_j crate(i,j)                                              */
+/* ======================================================================== */
+int rxo_rates(rxo_state *s)
+{
+    const rxo_mol *m = s->mol;
+    int n = m->nlev;
+    double tk = s->tkin;
+    memset(s->crate, 0, sizeof(double) * n * n);
+    double tot = 0.0;
+    for (int k = 0; k < RXO_MAXPART; k++) tot += s->density[k];
+    s->totdens = tot;
+    for (int id = 1; id <= RXO_MAXPART; id++) {
+        double dens = s->density[id - 1];
+        int ip = -1;
+        for (int q = 0; q < m->npart; q++) if (m->part_id[q] == id) ip = q;
+        if (ip < 0 || !(dens > 0.0)) continue;
+        int nt = m->ntemp[ip];
+        const double *T = m->temp[ip];
+        int mode, it = 0; double t = 0.0;   /* mode 0: single column it; 1: lerp */
+        if (nt <= 1)            { mode = 0; it = 0; }
+        else if (tk <= T[0])    { mode = 0; it = 0; }          /* "Tkin lower than..." */
+        else if (tk >= T[nt-1]) { mode = 0; it = nt - 1; }     /* "Tkin higher than..." */
+        else {
+            mode = 1;
+            for (it = 0; it < nt - 1; it++) if (tk > T[it] && tk <= T[it + 1]) break;
+            t = (tk - T[it]) / (T[it + 1] - T[it]);
+        }
+        for (int c = 0; c < m->ncoll[ip]; c++) {
+            const double *K = m->coll[ip] + (size_t)c * nt;
+            double colld = mode ? K[it] + t * (K[it + 1] - K[it]) : K[it];
+            if (colld < 0.0) return -1;
+            int iu = m->lcu[ip][c] - 1, il = m->lcl[ip][c] - 1;
+            s->crate[iu * n + il] += dens * colld;
+        }
+    }
+    for (int iup = 0; iup < n; iup++)
+        for (int ilo = 0; ilo < n; ilo++) {
+            double ediff = m->eterm[iup] - m->eterm[ilo];
+            if (ediff > 0.0) {
+                double e = ediff * FK / tk;
+                if (e >= EXPGUARD) s->crate[ilo * n + iup] = 0.0;
+                else s->crate[ilo * n + iup] =
+                    exp(-e) * (m->gstat[iup] / m->gstat[ilo]) * s->crate[iup * n + ilo];
+            }
+        }
+    for (int i = 0; i < n; i++) {
+        double c = 0.0;
+        for (int j = 0; j < n; j++) c += s->crate[i * n + j];
+        s->ctot[i] = c;
+    }
+    return 0;
+}
+
+/* backrad_, tbg>0 branch [BIN 0x1be30-0x1c390] */
+void rxo_backrad(rxo_state *s, double tbg)
+{
+    const rxo_mol *m = s->mol;
+    s->tbg = tbg;
+    for (int l = 0; l < m->nline; l++) {
+        double x = m->xnu[l];
+        double h = FK * x / tbg;
+        if (h >= EXPGUARD) s->backi[l] = SEED_F;
+        else s->backi[l] = THC * pow(x, 3.0) / (exp(h) - 1.0);   /* xnu**3. -> pow [BIN 0x1c04f] */
+        s->trj[l] = tbg;
+        s->totalb[l] = s->backi[l];
+    }
+}
+
+/* escprob_ [BIN 0xa9c0-0xad60] */
+double rxo_escprob(double tau, int method)
+{
+    double taur = 0.5 * tau;
+    if (method == 2) {                       /* LVG (hot path) */
+        if (fabs(taur) < 0.009999999776482582) return 1.0;
+        if (fabs(taur) < 7.0)
+            return 2.0 * (1.0 - exp(-2.3399999141693115 * taur)) / (4.679999828338623 * taur);
+        return 2.0 / (taur * 4.0 * sqrt(log(taur / 1.7724538498928541)));
+    } else if (method == 1) {                /* uniform sphere */
+        if (fabs(taur) < 0.10000000149011612)
+            return 1.0 - 0.75 * taur + (taur * taur) / 2.5 - (taur * taur * taur) / 6.0
+                   + (taur * taur * taur * taur) / 17.5;
+        if (fabs(taur) > 50.0) return 0.75 / taur;
+        return 0.75 / taur * (1.0 - 1.0 / (2.0 * (taur * taur)) +
+               (1.0 / taur + 1.0 / (2.0 * (taur * taur))) * exp(-2.0 * taur));
+    } else {                                 /* slab */
+        double x = 3.0 * tau;
+        if (fabs(x) < 0.10000000149011612) return 1.0 - 1.5 * (tau + tau * tau);
+        if (fabs(x) > 50.0) return 1.0 / x;
+        return (1.0 - exp(-x)) / x;
+    }
+}
+
+/* ---- LINPACK sgefa/sgesl as compiled (all REAL = double) ------------------
+ * [BIN sgefa_ 0xf3d0, sgesl_ 0xdb70, isamax_/sscal_/saxpy_]; column-major.  */
+static int lin_gefa(double *a, int lda, int n, int *ipvt)
+{
+    int info = 0;
+    for (int k = 0; k < n - 1; k++) {
+        int l = k; double smax = fabs(a[k + k * lda]);
+        for (int i = k + 1; i < n; i++) {            /* isamax: first maximum */
+            double v = fabs(a[i + k * lda]);
+            if (v > smax) { smax = v; l = i; }
+        }
+        ipvt[k] = l;
+        if (a[l + k * lda] == 0.0) { info = k + 1; continue; }
+        if (l != k) { double t = a[l + k * lda]; a[l + k * lda] = a[k + k * lda]; a[k + k * lda] = t; }
+        double t = -1.0 / a[k + k * lda];
+        for (int i = k + 1; i < n; i++) a[i + k * lda] = t * a[i + k * lda];   /* sscal */
+        for (int j = k + 1; j < n; j++) {
+            double tj = a[l + j * lda];
+            if (l != k) { a[l + j * lda] = a[k + j * lda]; a[k + j * lda] = tj; }
+            for (int i = k + 1; i < n; i++)                                      /* saxpy */
+                a[i + j * lda] = a[i + j * lda] + tj * a[i + k * lda];
+        }
+    }
+    ipvt[n - 1] = n - 1;
+    if (a[(n - 1) + (n - 1) * lda] == 0.0) info = n;
+    return info;
+}
+
+static void lin_gesl(const double *a, int lda, int n, const int *ipvt, double *b)
+{
+    for (int k = 0; k < n - 1; k++) {
+        int l = ipvt[k]; double t = b[l];
+        if (l != k) { b[l] = b[k]; b[k] = t; }
+        for (int i = k + 1; i < n; i++) b[i] = b[i] + t * a[i + k * lda];
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        b[k] = b[k] / a[k + k * lda];
+        double t = -b[k];
+        for (int i = 0; i < k; i++) b[i] = b[i] + t * a[i + k * lda];
+    }
+}
+
+/* lubksb_ as patched by pyradex [BIN 0x17cb0] + sgeir_ [BIN 0x16d50] (A.5):
+ * compact k x k copy, last row <- 1.0, rhs <- e_last, LU + solve; the second
+ * (residual) solve only feeds an accuracy estimate and does not change x.
+ * On a singular matrix sgeir_ returns without solving (x stays e_last).     */
+int rxo_lubksb(double *a, int n, double *x, int *ipvt)
+{
+    for (int j = 0; j < n; j++) a[(n - 1) + j * n] = 1.0;
+    for (int i = 0; i < n; i++) x[i] = 0.0;
+    x[n - 1] = 1.0;
+    int info = lin_gefa(a, n, n, ipvt);
+    if (info == 0) lin_gesl(a, n, n, ipvt, x);
+    return info;
+}
+
+/* matrix_ [BIN 0x17f70-0x1ae30].  yrate is column-major here
+ * too: Y(i,j) = yrate[i + j*n]; rows/cols nplus of the Fortran array are
+ * dropped because the patched lubksb_ never reads them.                     */
+void rxo_matrix(rxo_state *s, int niter, int *conv)
+{
+    const rxo_mol *mol = s->mol;
+    const int n = mol->nlev, L = mol->nline;
+    double *Y = s->yrate;
+#define YR(i, j) Y[(i) + (size_t)(j) * n]
+    /* 1. init [BIN 0x17fad-0x1852c] */
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) YR(i, j) = -SEED_D * s->totdens;
+
+    int nthick = 0, nfat = 0;
+    double cddv = s->cdmol / s->deltav;
+    /* 2. radiative terms */
+    if (niter == 0) {                                   /* [BIN 0x18547-0x186f5] */
+        for (int l = 0; l < L; l++) {
+            int m = mol->iupp[l] - 1, nn = mol->ilow[l] - 1;
+            double A = mol->aeinst[l], gm = mol->gstat[m], gn = mol->gstat[nn];
+            double etr = FK * mol->xnu[l] / s->trj[l];
+            double exr = (etr >= EXPGUARD) ? 0.0 : 1.0 / (exp(etr) - 1.0);
+            YR(m, m)   = YR(m, m)   + A * (1.0 + exr);
+            YR(nn, nn) = YR(nn, nn) + A * gm * exr / gn;
+            YR(m, nn)  = YR(m, nn)  - A * (gm / gn) * exr;
+            YR(nn, m)  = YR(nn, m)  - A * (1.0 + exr);
+        }
+    } else {                                            /* [BIN 0x199f0-0x19c26] */
+        for (int l = 0; l < L; l++) {
+            int m = mol->iupp[l] - 1, nn = mol->ilow[l] - 1;
+            double A = mol->aeinst[l], gm = mol->gstat[m], gn = mol->gstat[nn];
+            double x = mol->xnu[l];
+            double xt = pow(x, 3.0);              /* xnu**3. -> pow() */
+            s->taul[l] = cddv * (s->xpop[nn] * gm / gn - s->xpop[m]) / (FGAUS * xt / A);
+            if (s->taul[l] > THICK_D) nthick++;
+            if (s->taul[l] > FAT) nfat++;
+            double beta = rxo_escprob(s->taul[l], s->method);
+            double exr = s->totalb[l] * beta / (THC * xt);
+            YR(m, m)   = YR(m, m)   + A * (beta + exr);
+            /* operand order as compiled [BIN 0x19bcb-0x19be6]: ((exr*g_m)/g_n)*A */
+            YR(nn, nn) = YR(nn, nn) + exr * gm / gn * A;
+            YR(m, nn)  = YR(m, nn)  - A * (gm / gn) * exr;
+            YR(nn, m)  = YR(nn, m)  - A * (beta + exr);
+        }
+    }
+    (void)nfat;
+    /* 3. collisional terms [BIN 0x18713...] */
+    for (int i = 0; i < n; i++) {
+        YR(i, i) = YR(i, i) + s->ctot[i];
+        for (int j = 0; j < n; j++)
+            if (j != i) YR(i, j) = YR(i, j) - s->crate[j * n + i];
+    }
+    /* 4. solve [BIN 0x18cb8] */
+    memcpy(s->lu, Y, sizeof(double) * n * n);
+    s->lu_info = rxo_lubksb(s->lu, n, s->rhs, s->ipvt);
+    /* 5. normalise [BIN 0x18cbd-0x18ec4] */
+    double total = 0.0;
+    for (int i = 0; i < n; i++) total += s->rhs[i];
+    if (niter == 0) {
+        for (int i = 0; i < n; i++) {
+            double v = s->rhs[i] / total;
+            s->xpop[i] = (v > MINPOP) ? v : MINPOP;     /* max(minpop, v) */
+            s->xpopold[i] = s->xpop[i];
+        }
+    } else {
+        for (int i = 0; i < n; i++) {
+            double v = s->rhs[i] / total;
+            s->xpopold[i] = s->xpop[i];
+            s->xpop[i] = (v > MINPOP) ? v : MINPOP;
+        }
+    }
+    /* 6. Tex / tau [BIN 0x18ed7-0x19488] */
+    double tsum = 0.0;
+    for (int l = 0; l < L; l++) {
+        int m = mol->iupp[l] - 1, nn = mol->ilow[l] - 1;
+        double gm = mol->gstat[m], gn = mol->gstat[nn];
+        double x = mol->xnu[l];
+        double xt = pow(x, 3.0);              /* xnu**3. -> pow() */
+        double xm = s->xpop[m], xn = s->xpop[nn];
+        if (niter == 0) {
+            if (xn <= MINPOP || xm <= MINPOP) s->tex[l] = s->totalb[l];   /* sic */
+            else s->tex[l] = FK * x / log(xn * gm / (xm * gn));
+        } else {
+            double thistex;
+            if (xn <= MINPOP || xm <= MINPOP) thistex = s->tex[l];
+            else thistex = FK * x / log(xn * gm / (xm * gn));
+            if (s->taul[l] > THICK_F) tsum += fabs((thistex - s->tex[l]) / thistex);
+            s->tex[l] = 0.5 * (thistex + s->tex[l]);
+            s->taul[l] = cddv * (xn * gm / gn - xm) / (FGAUS * xt / mol->aeinst[l]);
+        }
+    }
+    /* 7. convergence [BIN 0x1949a-0x194e9] */
+    if (niter >= 10) {
+        if (nthick == 0) *conv = 1;
+        else if (tsum / nthick < CCRIT) *conv = 1;
+    }
+    /* 8. under-relaxation, always [BIN 0x19502-0x195bf] */
+    for (int i = 0; i < n; i++)
+        s->xpop[i] = RELAX_NEW * s->xpop[i] + RELAX_OLD * s->xpopold[i];
+#undef YR
+}
+
+/* Radex.run_radex [REF emcee/pyradex/core.py:896-925].
+ * NOTE (core.py:911-914): level_population is the whole maxlev=2999 COMMON
+ * array; entries beyond nlev are 0, so frac_level_diff contains 0/0 = NaN and
+ * frac_level_diff.sum() is NaN: the *relative* test can never pass.  Only the
+ * absolute test (sum|dx| < 1e-16) is live.  Restated faithfully.            */
+int rxo_run(rxo_state *s, int reuse_last, int miniter, int maxiter, int *converged)
+{
+    const int n = s->mol->nlev;
+    int iter = reuse_last ? 1 : 0;
+    int conv = 0;
+    double *last = (double *)malloc(sizeof(double) * n);
+    memcpy(last, s->xpop, sizeof(double) * n);
+    while (!conv) {
+        if (iter >= maxiter) break;
+        rxo_matrix(s, iter, &conv);
+        double dsum = 0.0;
+        for (int i = 0; i < n; i++) dsum += fabs(last[i] - s->xpop[i]);
+        int rel_ok = 0;   /* NaN < 1e-8 is False for every real molecule (nlev < 2999) */
+        if ((dsum < 1e-16 || rel_ok) && iter > miniter) break;
+        memcpy(last, s->xpop, sizeof(double) * n);
+        iter++;
+    }
+    free(last);
+    if (converged) *converged = conv;
+    return iter;
+}
+
+/* source_brightness - background_brightness
+ * [REF emcee/pyradex/core.py:986-1003, base_class.py:275-277] */
+void rxo_source_line_surfbrightness(const rxo_state *s, double *out)
+{
+    const rxo_mol *m = s->mol;
+    for (int l = 0; l < m->nline; l++) {
+        double ftau = exp(-s->taul[l]);
+        double x = m->xnu[l];
+        double xt = pow(x, 3.0);              /* xnu**3. -> pow() */
+        double earg = FK_PY * x / s->tex[l];
+        double bnutex = THC_PY * xt / (exp(earg) - 1.0);
+        double toti = s->backi[l] * ftau + bnutex * (1.0 - ftau);
+        out[l] = toti - s->backi[l];
+    }
+}
+
+/* ======================================================================== */
+/* Driver restatement                                                        */
+/* ======================================================================== */
+
+/* Radex.set_params(density={'oH2','pH2'}, column, temperature)
+ * [REF emcee/pyradex/core.py:388-438, 489-579, 727-753, 767-787].
+ * Returns 1 where the reference raises ValueError.                          */
+static int set_params_lvg(rxo_state *s, double n_h2, double column, double temperature)
+{
+    const rxo_mol *m = s->mol;
+    const double fortho = 3.0 / (1.0 + 3.0);             /* emcee_radex.py:95-96 */
+    double oh2 = fortho * n_h2, ph2 = (1.0 - fortho) * n_h2;
+    int has_h2 = 0, has_op = 0;
+    for (int q = 0; q < m->npart; q++) {
+        if (m->part_id[q] == 1) has_h2 = 1;
+        if (m->part_id[q] == 2 || m->part_id[q] == 3) has_op = 1;
+    }
+    s->tkin = temperature;                               /* core.py:401-402 */
+    for (int k = 0; k < RXO_MAXPART; k++) s->density[k] = 0.0;
+    s->density[1] = ph2; s->density[2] = oh2;            /* core.py:525-528 */
+    if (has_h2) {                                        /* core.py:551-554 */
+        s->density[0] = s->density[1] + s->density[2];
+        s->density[1] = 0.0; s->density[2] = 0.0;
+    } else if (has_op) s->density[0] = 0.0;              /* core.py:555-556 */
+    /* _validate_colliders (base_class.py:224-263): some file collider must have density>0 */
+    int okc = 0;
+    for (int q = 0; q < m->npart; q++) if (s->density[m->part_id[q] - 1] > 0.0) okc = 1;
+    if (!okc) return 1;
+    if (column < 1e5 || column > 1e25) return 1;         /* core.py:771-772 */
+    s->cdmol = column;
+    if (temperature <= 0.0 || temperature > 1e4) return 1; /* core.py:734-735 */
+    if (rxo_rates(s) != 0) return 1;                     /* readdata() core.py:570,744 */
+    return 0;
+}
+
+static int solve_component(rxo_state *s, const rxo_source *src, const double *p4,
+                           double *sb /* [nline] */, int *niter, int *hitmax)
+{
+    double n_h2 = pow(10.0, p4[0]), T = pow(10.0, p4[1]), N = pow(10.0, p4[2]);
+    if (set_params_lvg(s, n_h2, N, T)) return 1;
+    (void)src;
+    int conv = 0;
+    /* cold start: reuse_last=False semantics (history-free engine) */
+    int it = rxo_run(s, 0, 10, 200, &conv);
+    if (niter) *niter += it;
+    if (hitmax && it >= 200 && !conv) *hitmax = 1;
+    rxo_source_line_surfbrightness(s, sb);
+    return 0;
+}
+
+/* model_lvg [REF emcee/emcee_radex.py:120-130; emcee_radex_2comp.py:122-147] */
+int rxo_model_lvg(rxo_state *s, const rxo_source *src, const double *p,
+                  double *flux_out, int *niter_out, int *maxiter_hit)
+{
+    const int L = s->mol->nline;
+    double *sb = (double *)malloc(sizeof(double) * L);
+    if (niter_out) *niter_out = 0;
+    if (maxiter_hit) *maxiter_hit = 0;
+    for (int j = 0; j < src->nJ; j++) flux_out[j] = 0.0;
+    for (int c = 0; c < src->ncomp; c++) {
+        const double *p4 = p + 4 * c;
+        if (solve_component(s, src, p4, sb, niter_out, maxiter_hit)) { free(sb); return 1; }
+        double size = pow(10.0, p4[3]);
+        for (int j = 0; j < src->nJ; j++) {
+            int idx = src->Jup[j] - 1;
+            double v = (idx >= 0 && idx < L) ? sb[idx] : NAN;
+            double f = v * size * 1.0 * 1e23;            /* .to(Jy km/s) == x1e23 */
+            flux_out[j] = (c == 0) ? f : flux_out[j] + f;
+        }
+    }
+    free(sb);
+    return 0;
+}
+
+/* lnprior [REF emcee/emcee_radex.py:169-175; emcee_radex_2comp.py:199-234] */
+double rxo_lnprior(const rxo_source *src, const double *p)
+{
+    const int ndim = 4 * src->ncomp;
+    const double *b = src->bounds;
+    for (int k = 0; k < ndim; k++)
+        if (p[k] > b[2 * k + 1] || p[k] < b[2 * k]) return -INFINITY;
+    if (src->ncomp == 1) {
+        if ((p[2] - p[0] >= 17.5) || (p[2] - p[0] <= 10.0)) return -INFINITY;
+        return 0.0;
+    }
+    if (p[5] <= p[1]) return -INFINITY;
+    if ((p[2] - p[0]) >= 18.0 || (p[2] - p[0]) <= 9.0 ||
+        (p[6] - p[4]) >= 18.0 || (p[6] - p[4]) <= 9.0) return -INFINITY;
+    if (p[3] < p[7]) return -INFINITY;
+    double logp = 0.0;
+    for (int k = 0; k < ndim; k++) {
+        if (k == 1 && !isnan(src->T_d)) {
+            double T_kin = pow(10.0, p[k]);
+            if (src->T_d <= 0) return -INFINITY;
+            double sigma = 1.0 * src->T_d;
+            double z = (T_kin - src->T_d) / sigma;
+            logp += (-0.5 * (z * z) - log(sigma * sqrt(2.0 * M_PI)));
+        } else {
+            logp += -(b[2 * k + 1] - b[2 * k]);
+        }
+    }
+    return logp;
+}
+
+/* lnlike [REF emcee/emcee_radex.py:132-167; emcee_radex_2comp.py:169-196] */
+static double lnlike(rxo_state *s, const rxo_source *src, const double *p,
+                     int *status, int *niter)
+{
+    double model[64];
+    int hit = 0;
+    if (rxo_model_lvg(s, src, p, model, niter, &hit)) { *status = RXO_INVALID; return -INFINITY; }
+    *status = hit ? RXO_MAXITER : RXO_OK;
+    for (int j = 0; j < src->nJ; j++)
+        if (!isfinite(src->flux[j]) || !isfinite(model[j])) { *status = RXO_INVALID; return -INFINITY; }
+    double chi2 = 0.0, logterm = 0.0;
+    const double max_safe = sqrt(1.7976931348623157e308) / 10.0;
+    for (int j = 0; j < src->nJ; j++) {
+        double e = fabs(src->eflux[j]);
+        if (!(e > 1e-12)) e = isnan(e) ? e : 1e-12;      /* np.maximum propagates NaN */
+        if (!isfinite(e)) { *status = RXO_INVALID; return -INFINITY; }
+        double r = (src->flux[j] - model[j]) / e;
+        if (!isfinite(r) || fabs(r) > max_safe) { *status = RXO_INVALID; return -INFINITY; }
+        chi2 += r * r;
+        logterm += log(e);
+    }
+    return -0.5 * (chi2 + 2.0 * logterm);
+}
+
+/* lnprob [REF emcee/emcee_radex.py:177-181; emcee_radex_2comp.py:237-244] */
+double rxo_lnprob(rxo_state *s, const rxo_source *src, const double *p,
+                  int *status, int *niter_out)
+{
+    int st = RXO_OK, nit = 0;
+    double lp = rxo_lnprior(src, p);
+    if (!isfinite(lp)) {
+        if (status) *status = RXO_PRIOR;
+        if (niter_out) *niter_out = 0;
+        return -INFINITY;
+    }
+    double ll = lnlike(s, src, p, &st, &nit);
+    if (status) *status = st;
+    if (niter_out) *niter_out = nit;
+    if (src->ncomp == 2 && !isfinite(ll)) return -INFINITY;
+    return lp + ll;
+}
+
+int rxo_lnprob_batch(const rxo_mol *m, int method, double deltav_kms,
+                     const rxo_source *src, int N, const double *params,
+                     double *lnp, int32_t *status, int32_t *niter, int nthreads)
+{
+    const int ndim = 4 * src->ncomp;
+    if (src->nJ > 64) return -1;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        rxo_state *s = rxo_state_new(m, method, deltav_kms);
+        rxo_backrad(s, src->tbg);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int w = 0; w < N; w++) {
+            int st, nit;
+            lnp[w] = rxo_lnprob(s, src, params + (size_t)w * ndim, &st, &nit);
+            if (status) status[w] = st;
+            if (niter) niter[w] = nit;
+        }
+        rxo_state_free(s);
+    }
+    (void)nthreads;
+    return 0;
+}
+
+int rxo_model_flux_batch(const rxo_mol *m, int method, double deltav_kms,
+                         const rxo_source *src, int N, const double *params,
+                         double *flux, int32_t *status, int32_t *niter, int nthreads)
+{
+    const int ndim = 4 * src->ncomp;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        rxo_state *s = rxo_state_new(m, method, deltav_kms);
+        rxo_backrad(s, src->tbg);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int w = 0; w < N; w++) {
+            int nit = 0, hit = 0;
+            int bad = rxo_model_lvg(s, src, params + (size_t)w * ndim,
+                                    flux + (size_t)w * src->nJ, &nit, &hit);
+            if (bad) for (int j = 0; j < src->nJ; j++) flux[(size_t)w * src->nJ + j] = NAN;
+            if (status) status[w] = bad ? RXO_INVALID : (hit ? RXO_MAXITER : RXO_OK);
+            if (niter) niter[w] = nit;
+        }
+        rxo_state_free(s);
+    }
+    (void)nthreads;
+    return 0;
+}
+
+int rxo_solve_state(const rxo_mol *m, int method, double deltav_kms, double tbg,
+                    const double *dens, double tkin, double cdmol,
+                    double *xpop, double *tex, double *tau, int *converged)
+{
+    rxo_state *s = rxo_state_new(m, method, deltav_kms);
+    rxo_backrad(s, tbg);
+    for (int k = 0; k < RXO_MAXPART; k++) s->density[k] = dens[k];
+    s->tkin = tkin; s->cdmol = cdmol;
+    if (rxo_rates(s) != 0) { rxo_state_free(s); return -1; }
+    int it = rxo_run(s, 0, 10, 200, converged);
+    memcpy(xpop, s->xpop, sizeof(double) * m->nlev);
+    memcpy(tex, s->tex, sizeof(double) * m->nline);
+    memcpy(tau, s->taul, sizeof(double) * m->nline);
+    rxo_state_free(s);
+    return it;
+}

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by EXECUTING the reference's radex.so (container only).
+
+    python tests/golden/make_ref_vectors.py
+
+Writes tests/golden/ref_escprob.json, ref_backrad.json, ref_lubksb.json,
+ref_matrix.json.  Every number in them was computed by the reference's own
+machine code (/root/reference/emcee/pyradex/radex/radex.so, routines
+escprob_, backrad_, lubksb_, matrix_) loaded through oracle/macho_ref.py; the
+iteration driver around matrix_ follows emcee/pyradex/core.py:896-925.
+
+Inputs that the reference would obtain from readdata_ (which cannot run here:
+it needs libgfortran's list-directed READ) are poked into the COMMON blocks
+directly: level/line tables parsed from the committed LAMDA-format files and
+crate/ctot from the oracle's rate routine.  They are stored in the fixtures by
+value where small, otherwise they are re-derivable from the committed .dat
+file, so the vectors stay self-contained.
+
+A vector is rejected if any trapped import (Fortran I/O, STOP) fired.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O            # noqa: E402
+from oracle.macho_ref import RefRadex, MAXLEV   # noqa: E402
+from radex_emcee_amd.molecule import SYNTH_CO_PATH   # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOY_PATH = os.path.join(HERE, "toy6.dat")
+
+
+def fl(a):
+    return [float(x) for x in np.asarray(a, dtype=np.float64).ravel()]
+
+
+def poke_molecule(R, v, mol):
+    v["imolec_hdr"][0] = mol.nlev
+    v["imolec_hdr"][1] = mol.nline
+    v["iupp"][:mol.nline] = mol.iupp
+    v["ilow"][:mol.nline] = mol.ilow
+    v["eterm"][:mol.nlev] = mol.eterm
+    v["gstat"][:mol.nlev] = mol.gstat
+    v["aeinst"][:mol.nline] = mol.aeinst
+    v["xnu"][:mol.nline] = mol.xnu
+    v["spfreq"][:mol.nline] = mol.spfreq
+
+
+def poke_physics(R, v, st, mol, method):
+    n = mol.nlev
+    v["method"][0] = method
+    for k in range(9):
+        v["density"][k] = st.s.density[k]
+    v["tkin"][0] = st.s.tkin
+    v["cdmol"][0] = st.s.cdmol
+    v["deltav"][0] = st.s.deltav
+    v["totdens"][0] = st.s.totdens
+    crate = st.arr("crate").reshape(n, n)          # crate[i, j] = rate i->j
+    cr = v["crate"]
+    for j in range(n):                              # Fortran crate(i,j) column-major
+        cr[j * MAXLEV:j * MAXLEV + n] = crate[:, j]
+    v["ctot"][:n] = st.arr("ctot")
+    v["xpop"][:n] = 0.0
+    v["tex"][:mol.nline] = 0.0
+    v["taul"][:mol.nline] = 0.0
+
+
+def run_reference_loop(R, v, mol, reuse_last=False, miniter=10, maxiter=200):
+    """core.py:896-925 around the reference's matrix_."""
+    n = mol.nlev
+    it = 1 if reuse_last else 0
+    conv = 0
+    last = v["xpop"][:n].copy()
+    snaps = {}
+    while not conv:
+        if it >= maxiter:
+            break
+        conv = R.matrix(it, conv)
+        x = v["xpop"][:n]
+        if it in (0, 1, 2, 5, 10):
+            snaps[str(it)] = dict(xpop=fl(x), tex=fl(v["tex"][:mol.nline]),
+                                  taul=fl(v["taul"][:mol.nline]))
+        dsum = np.abs(last - x).sum()
+        if dsum < 1e-16 and it > miniter:     # relative test is NaN-dead (see oracle)
+            break
+        last = x.copy()
+        it += 1
+    return it, conv, snaps
+
+
+def main():
+    assert os.path.exists(TOY_PATH), "toy6.dat missing"
+    R = RefRadex()
+    v = R.views()
+
+    # ---- escprob_ ----------------------------------------------------------
+    taus = [0.0, 1e-8, 1e-3, 0.0199, 0.02, 0.0201, 0.19, 0.2, 0.21, 0.5, 1.0, 3.3, 7.7,
+            13.99, 14.0, 14.01, 33.3, 99.9, 100.0, 100.1, 1e3, 1e5, 1e8,
+            -1e-3, -0.3, -2.0, -13.0, 16.6667, 16.7]
+    esc = []
+    for method in (1, 2, 3):
+        for t in taus:
+            esc.append(dict(method=method, tau=t, beta=R.escprob(t, method)))
+    # LVG log-of-negative branch -> NaN (maser, taur <= -7)
+    esc.append(dict(method=2, tau=-20.0, beta=R.escprob(-20.0, 2)))
+    assert not R.trap_log, R.trap_log
+    json.dump(dict(source="radex.so:_escprob_", cases=esc),
+              open(os.path.join(HERE, "ref_escprob.json"), "w"), indent=0, allow_nan=True)
+
+    # ---- lubksb_ ------------------------------------------------------------
+    rng = np.random.default_rng(20251003)
+    lucases = []
+    for n in (3, 6, 17, 41):
+        for rep in range(2):
+            A = rng.standard_normal((n, n)) * 10.0 ** rng.uniform(-6, 0, size=(n, 1))
+            A[np.arange(n), np.arange(n)] += np.abs(A).sum(1)      # rate-matrix-like
+            big = np.zeros((n + 1, n + 1), order="F")
+            big[:n, :n] = A
+            x = R.lubksb(big)[:n]
+            lucases.append(dict(n=n, A=fl(A), x=fl(x)))
+    assert not R.trap_log, R.trap_log
+    json.dump(dict(source="radex.so:_lubksb_ (n=nlev+1, np=nlev+1)", layout="A row-major",
+                   cases=lucases), open(os.path.join(HERE, "ref_lubksb.json"), "w"), indent=0)
+
+    # ---- backrad_ + matrix_ ---------------------------------------------------
+    molfiles = {"co_synth": SYNTH_CO_PATH, "toy6": TOY_PATH}
+    cases = [
+        # (mol, method, tbg, {partner id: density}, tkin, cdmol)
+        ("co_synth", 2, 2.73, {2: 0.25e4, 3: 0.75e4}, 30.0, 1e14),
+        ("co_synth", 2, 2.7315 * 3.5, {2: 0.25 * 10 ** 3.5, 3: 0.75 * 10 ** 3.5}, 100.0, 10 ** 17.5),
+        ("co_synth", 2, 2.7315 * 4.911, {2: 0.25 * 10 ** 4.2, 3: 0.75 * 10 ** 4.2}, 10 ** 2.4, 10 ** 17.5),
+        ("co_synth", 2, 9.56, {2: 0.25e2, 3: 0.75e2}, 12.0, 10 ** 19.4),       # thick, cold, sub-thermal
+        ("co_synth", 2, 9.56, {2: 0.25e7, 3: 0.75e7}, 900.0, 10 ** 19.5),     # thick, hot, dense
+        ("co_synth", 2, 9.56, {2: 0.25 * 10 ** 5.5, 3: 0.75 * 10 ** 5.5}, 10 ** 1.3, 10 ** 15.6),
+        ("co_synth", 2, 9.56, {2: 0.25 * 10 ** 2.3, 3: 0.75 * 10 ** 2.3}, 500.0, 10 ** 18.9),
+        ("co_synth", 1, 2.73, {2: 0.25e4, 3: 0.75e4}, 20.0, 1e15),             # sphere
+        ("co_synth", 3, 2.73, {2: 0.25e4, 3: 0.75e4}, 20.0, 1e16),             # slab
+        ("co_synth", 2, 2.73, {2: 1e3, 3: 0.0}, 3000.5, 1e13),                 # T above table
+        ("co_synth", 2, 2.73, {2: 1e3, 3: 2e3}, 1.5, 1e13),                    # T below table
+        ("toy6", 2, 2.73, {1: 1e4}, 25.0, 1e14),
+        ("toy6", 2, 5.0, {1: 3e5}, 70.0, 1e17),
+        ("toy6", 1, 2.73, {1: 1e3}, 10.0, 1e16),
+    ]
+    out_b, out_m = [], []
+    mols = {k: O.Molecule(p) for k, p in molfiles.items()}
+    # walkers drawn like BASELINE config 2 (uniform in the prior box, z=2.5); keep the
+    # first three that exhaust maxiter=200 in the oracle plus eight others
+    rng2 = np.random.default_rng(1234)
+    tbg2 = 2.7315 * 3.5
+    lo = np.array([2.0, np.log10(tbg2), 15.5])
+    hi = np.array([7.0, 3.0, 19.5])
+    n200 = nother = 0
+    while n200 < 3 or nother < 8:
+        p = lo + (hi - lo) * rng2.random(3)
+        if not (10.0 < p[2] - p[0] < 17.5):
+            continue
+        dens = {2: 0.25 * 10 ** p[0], 3: 0.75 * 10 ** p[0]}
+        r = O.solve_state(mols["co_synth"], tbg2, dens, 10 ** p[1], 10 ** p[2])
+        if r["niter"] >= 200 and n200 < 3:
+            n200 += 1
+        elif r["niter"] < 200 and nother < 8:
+            nother += 1
+        else:
+            continue
+        cases.append(("co_synth", 2, tbg2, dens, 10 ** p[1], 10 ** p[2]))
+    for name, method, tbg, dens, tkin, cdmol in cases:
+        mol = mols[name]
+        st = O.State(mol, method, 1.0)
+        st.set_density(dens)
+        st.s.tkin = tkin
+        st.s.cdmol = cdmol
+        assert st.rates() == 0
+        # wipe + poke
+        poke_molecule(R, v, mol)
+        poke_physics(R, v, st, mol, method)
+        v["tbg"][0] = tbg
+        R.backrad()
+        out_b.append(dict(mol=name, tbg=tbg, backi=fl(v["backi"][:mol.nline]),
+                          totalb=fl(v["totalb"][:mol.nline]), trj=fl(v["trj"][:mol.nline])))
+        it, conv, snaps = run_reference_loop(R, v, mol)
+        assert not R.trap_log, (name, R.trap_log)
+        out_m.append(dict(mol=name, method=method, tbg=tbg,
+                          density={str(k): float(x) for k, x in dens.items()},
+                          tkin=tkin, cdmol=cdmol, deltav_kms=1.0,
+                          niter=int(it), conv=int(conv), snapshots=snaps,
+                          xpop=fl(v["xpop"][:mol.nlev]), tex=fl(v["tex"][:mol.nline]),
+                          taul=fl(v["taul"][:mol.nline])))
+        print(name, method, tkin, cdmol, "-> niter", it, "conv", conv)
+    json.dump(dict(source="radex.so:_backrad_", cases=out_b),
+              open(os.path.join(HERE, "ref_backrad.json"), "w"), indent=0)
+    json.dump(dict(source="radex.so:_matrix_ driven by core.py:896-925 (cold start)",
+                   note="crate/ctot poked from oracle rxo_rates(); see make_ref_vectors.py",
+                   cases=out_m), open(os.path.join(HERE, "ref_matrix.json"), "w"), indent=0)
+    print("traps:", R.trap_log)
+
+
+if __name__ == "__main__":
+    main()
