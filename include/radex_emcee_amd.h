@@ -1,0 +1,163 @@
+/*
+ * radex_emcee_amd.h -- C ABI of the MI355X-native batched RADEX LVG
+ * likelihood engine (libradex_emcee_amd.so, HIP / gfx950).
+ *
+ * This is the drop-in boundary for ONE hot path of yangcht/radex_emcee: the
+ * per-walker RADEX escape-probability solve inside lnlike/model_lvg.  Each
+ * entry point names the reference interface it replaces (paths relative to
+ * /root/reference).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - all floating point is IEEE double (the reference is all-double);
+ *   - "params" is row-major [N][ndim], ndim = 4*ncomp, log10 of
+ *     (n_H2 [cm^-3], T_kin [K], N_CO/dv [cm^-2 (km/s)^-1], size [sr]) per
+ *     component, exactly the vector p that emcee hands to lnprob
+ *     (emcee/emcee_radex.py:120-121, emcee/emcee_radex_2comp.py:122-125);
+ *   - functions return 0 on success, a negative RX_E_* code on failure and
+ *     never throw; rx_last_error() gives the message;
+ *   - there is NO CPU fallback: every compute entry point needs a HIP device
+ *     and fails with RX_E_NODEVICE otherwise;
+ *   - a handle is single-caller; use one handle per GPU / per thread.
+ */
+#ifndef RADEX_EMCEE_AMD_H
+#define RADEX_EMCEE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RX_ABI_VERSION 1
+#define RX_MAX_SOURCES 64      /* sources resident in one handle (config 3: 16) */
+#define RX_MAX_NJ      32      /* observed lines per source                     */
+#define RX_MAX_LEVELS  64      /* one level per lane of a 64-wide wavefront     */
+#define RX_MAX_LINES   64
+
+/* per-walker status (int32), mirrors the reference's error behaviour:
+ *   OK       converged (Fortran conv flag or the python delta-pop test)
+ *   MAXITER  stopped at maxiter=200 unconverged; result used silently
+ *            (emcee/pyradex/core.py:904-907)
+ *   INVALID  the reference would raise ValueError (core.py:734-735,771-772)
+ *            or produce non-finite model/residuals -> lnlike = -inf
+ *            (emcee/emcee_radex.py:134-161)
+ *   PRIOR    lnprior = -inf, solver not run (emcee/emcee_radex.py:179-180)   */
+enum { RX_OK = 0, RX_MAXITER = 1, RX_INVALID = 2, RX_PRIOR = 3 };
+
+enum {
+    RX_E_ARG      = -1,   /* bad argument                                   */
+    RX_E_IO       = -2,   /* molecular data file missing / malformed        */
+    RX_E_UNSUPP   = -3,   /* molecule outside the kernel's limits           */
+    RX_E_NODEVICE = -4,   /* no usable HIP device                           */
+    RX_E_HIP      = -5,   /* HIP runtime error                              */
+    RX_E_STATE    = -6    /* source not set, etc.                           */
+};
+
+typedef struct rx_handle rx_handle;
+
+/* Replaces the pyradex.Radex(...) constructor as called by init_radex()
+ * (emcee/emcee_radex.py:104-117, emcee/pyradex/core.py:209-386):
+ *   lamda_path  = datapath + species + ".dat" (LAMDA format, readdata_)
+ *   method      = escapeProbGeom: 1 sphere, 2 lvg, 3 slab (core.py:690-700)
+ *   deltav_kms  = deltav (core.py:447-454)
+ *   device      = HIP device ordinal (>= 0)
+ * Returns NULL on failure with a message in err.                            */
+rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms,
+                     int device, char *err, size_t errlen);
+void rx_destroy(rx_handle *h);
+const char *rx_last_error(const rx_handle *h);
+int rx_abi_version(void);
+
+/* Molecule introspection (Radex.level_population.size etc.).               */
+int rx_nlev(const rx_handle *h);
+int rx_nline(const rx_handle *h);
+int rx_npart(const rx_handle *h);
+/* collision partner ids in file order: 1=H2 2=pH2 3=oH2 4=e 5=H 6=He 7=H+
+ * (core.py:476-482).  out[rx_npart].                                        */
+int rx_partner_ids(const rx_handle *h, int32_t *out);
+/* line data, out[rx_nline]: xnu [cm^-1] = E_up - E_low (core.py:1024-1029),
+ * spfreq [GHz] (Radex.frequency), 1-based upper/lower level indices.        */
+int rx_line_data(const rx_handle *h, double *xnu, double *spfreq,
+                 int32_t *iupp, int32_t *ilow);
+
+/* Ortho fraction used to split n_H2 into oH2/pH2 densities; default 0.75 =
+ * opr/(1+opr) with opr = 3 (emcee/emcee_radex.py:95-96).                    */
+int rx_set_fortho(rx_handle *h, double fortho);
+/* Iteration limits of Radex.run_radex (core.py:460-463): default 10 / 200.  */
+int rx_set_iteration_limits(rx_handle *h, int miniter, int maxiter);
+
+/* Replaces R.set_params(tbg=...) -> backrad_ (emcee/emcee_radex.py:419,
+ * core.py:845-854) together with the per-source closure arguments of lnprob
+ * (args=(Jup, flux, eflux), kwargs={'bounds', 'T_d'}:
+ * emcee/emcee_radex.py:483-488, emcee/emcee_radex_2comp.py:557-563).
+ *   src     slot 0..RX_MAX_SOURCES-1
+ *   Jup     upper-level J of each observed line (model index = Jup-1)
+ *   bounds  [4*ncomp][2] (lo, hi)
+ *   T_d     dust temperature for the 2-component Gaussian prior; NaN = None  */
+int rx_set_source(rx_handle *h, int src, double tbg, int nJ, const int32_t *Jup,
+                  const double *flux, const double *eflux, const double *bounds,
+                  int ncomp, double T_d);
+
+/* Replaces lnprob(p, Jup, flux, eflux, bounds[, T_d]) called once per walker
+ * through pool.map (emcee/emcee_radex.py:177-181,
+ * emcee/emcee_radex_2comp.py:237-244) by ONE launch over N walkers.
+ *   src_index  per-walker source slot, or NULL = slot 0 for every walker;
+ *              all referenced sources must have the same ncomp
+ *   lnp        [N] log-probability, -inf allowed
+ *   status     [N] RX_* status, may be NULL
+ *   niter      [N] iterations (_iter_counter summed over components), may be NULL
+ * Host-pointer form: copies in/out through handle-owned staging buffers.    */
+int rx_lnprob_batch(rx_handle *h, int N, const double *params,
+                    const int32_t *src_index, double *lnp, int32_t *status,
+                    int32_t *niter);
+/* Device-pointer form: all pointers are HIP device pointers on the handle's
+ * device, `stream` is a hipStream_t (NULL = default stream); asynchronous.  */
+int rx_lnprob_batch_device(rx_handle *h, int N, const double *d_params,
+                           const int32_t *d_src_index, double *d_lnp,
+                           int32_t *d_status, int32_t *d_niter, void *stream);
+
+/* Replaces model_lvg(Jup, p, R) (emcee/emcee_radex.py:120-130,
+ * emcee/emcee_radex_2comp.py:122-147): flux_out[N][nJ(src)] in Jy km/s.
+ * Walkers the reference would reject with ValueError get NaN fluxes and
+ * status RX_INVALID.  No prior is applied.                                   */
+int rx_model_flux_batch(rx_handle *h, int src, int N, const double *params,
+                        double *flux_out, int32_t *status, int32_t *niter);
+int rx_model_flux_batch_device(rx_handle *h, int src, int N, const double *d_params,
+                               double *d_flux_out, int32_t *d_status,
+                               int32_t *d_niter, void *stream);
+
+/* Replaces Radex(...).run_radex() + the state properties used by the
+ * reference's known-answer tests (emcee/pyradex/tests/test_radex.py:99-115):
+ * physical (linear) inputs, cold start.
+ *   tkin[N], cdmol[N], dens[N][rx_npart] (file partner order, cm^-3)
+ * Outputs (each may be NULL): xpop[N][nlev], tex[N][nline], tau[N][nline],
+ * sb[N][nline] = source_line_surfbrightness (erg s^-1 cm^-2 Hz^-1 sr^-1).
+ * Uses the background of source slot `src`.  Host pointers.                 */
+int rx_solve_batch(rx_handle *h, int src, int N, const double *tkin,
+                   const double *cdmol, const double *dens, double *xpop,
+                   double *tex, double *tau, double *sb, int32_t *status,
+                   int32_t *niter);
+
+/* Replaces lubksb_(a, n, np, indx, b) as patched by pyradex (radex.so lubksb_ -> sgeir_,
+ * SURVEY.md A.5; called from matrix_): for each of N systems A[n][n] (row-major, n <= the
+ * handle's padded level count) the last row is replaced by ones, rhs = e_last, and the
+ * solution of the LU with partial pivoting is returned in x[N][n].  Host pointers.  Exposed
+ * so the pivoted solve can be checked on its own against the reference's lubksb_ vectors. */
+int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x);
+
+/* Kernel timing hook for bench.py: runs rx_lnprob_batch_device `reps` times
+ * back-to-back on `stream`, bracketing every launch with HIP events on that
+ * same stream, and returns the mean per-launch kernel time in milliseconds.  */
+int rx_time_lnprob_device(rx_handle *h, int N, const double *d_params,
+                          const int32_t *d_src_index, double *d_lnp,
+                          int32_t *d_status, int32_t *d_niter, void *stream,
+                          int reps, double *ms_mean_out);
+
+/* Name of the dominant kernel symbol for the loaded molecule (profiles/).   */
+const char *rx_kernel_name(const rx_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADEX_EMCEE_AMD_H */

@@ -1,0 +1,83 @@
+"""ctypes loader for libradex_emcee_amd.so (the HIP/gfx950 engine).
+
+There is no CPU fallback: if the shared library is missing this raises, and
+every compute entry point of the library itself fails without a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libradex_emcee_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+RX_OK, RX_MAXITER, RX_INVALID, RX_PRIOR = 0, 1, 2, 3
+RX_MAX_SOURCES = 64
+RX_MAX_NJ = 32
+
+# every symbol include/radex_emcee_amd.h declares
+EXPORTS = [
+    "rx_abi_version", "rx_create", "rx_destroy", "rx_last_error", "rx_nlev", "rx_nline",
+    "rx_npart", "rx_partner_ids", "rx_line_data", "rx_set_fortho", "rx_set_iteration_limits",
+    "rx_set_source", "rx_lnprob_batch", "rx_lnprob_batch_device", "rx_model_flux_batch",
+    "rx_model_flux_batch_device", "rx_solve_batch", "rx_lubksb_batch", "rx_time_lnprob_device",
+    "rx_kernel_name",
+]
+
+
+class EngineLibraryMissing(ImportError):
+    pass
+
+
+def build(fast: bool = False, force: bool = False) -> str:
+    """Compile the HIP extension in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("rx_api.hip", "rx_kernel.hip.inc", "rx_tables.h")]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "radex_emcee_amd.h"))
+    stale = (not os.path.exists(LIB_PATH)
+             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
+    if force or stale:
+        cmd = ["make", "-C", CSRC, "-B"] + (["FAST=1"] if fast else [])
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineLibraryMissing(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  radex_emcee_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.rx_abi_version.restype = C.c_int
+    L.rx_create.restype = vp
+    L.rx_create.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_char_p, C.c_size_t]
+    L.rx_destroy.argtypes = [vp]
+    L.rx_destroy.restype = None
+    L.rx_last_error.restype = C.c_char_p
+    L.rx_last_error.argtypes = [vp]
+    L.rx_kernel_name.restype = C.c_char_p
+    L.rx_kernel_name.argtypes = [vp]
+    for f in (L.rx_nlev, L.rx_nline, L.rx_npart):
+        f.argtypes = [vp]
+    L.rx_partner_ids.argtypes = [vp, ip]
+    L.rx_line_data.argtypes = [vp, dp, dp, ip, ip]
+    L.rx_set_fortho.argtypes = [vp, C.c_double]
+    L.rx_set_iteration_limits.argtypes = [vp, C.c_int, C.c_int]
+    L.rx_set_source.argtypes = [vp, C.c_int, C.c_double, C.c_int, ip, dp, dp, dp, C.c_int, C.c_double]
+    L.rx_lnprob_batch.argtypes = [vp, C.c_int, dp, ip, dp, ip, ip]
+    L.rx_lnprob_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.rx_model_flux_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, ip]
+    L.rx_model_flux_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.rx_solve_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip]
+    L.rx_lubksb_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    L.rx_time_lnprob_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
+    _lib = L
+    return L

@@ -1,0 +1,722 @@
+// rx_api.hip -- host side of libradex_emcee_amd.so: LAMDA parsing, table
+// construction, HIP memory/stream plumbing and the extern "C" ABI declared in
+// include/radex_emcee_amd.h.  gfx950 only; there is no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/radex_emcee_amd.h"
+#include "rx_kernel.hip.inc"
+#include "rx_tables.h"
+
+// Padded level counts the solve kernel is instantiated for (one fully unrolled
+// kernel each); rx_create picks the smallest one >= nlev.  41 = CO.
+#ifndef RX_NL_LIST
+#define RX_NL_LIST 8, 16, 24, 32, 41, 48, 56, 64
+#define RX_NL_CASES RX_CASE(8) RX_CASE(16) RX_CASE(24) RX_CASE(32) RX_CASE(41) RX_CASE(48) RX_CASE(56) RX_CASE(64)
+#endif
+
+namespace {
+
+// Fortran-side constants used by backrad_ / matrix_
+constexpr double H_FK = 1.4387809925261357;
+constexpr double H_THC = 3.972907393443411e-16;
+constexpr double H_FGAUS = 26.753802360251857;
+constexpr double H_SEED_F = 1.0000000031710769e-30;
+// astropy CODATA-2018, emcee/pyradex/core.py:981-984
+constexpr double H_THC_PY = 3.9728917142978573e-16;
+constexpr double H_FK_PY = 1.4387768775039338;
+
+struct Partner {
+    int id = 0, ncoll = 0, ntemp = 0;
+    std::vector<double> temps;
+    std::vector<int> lcu, lcl;
+    std::vector<double> coll;   // [ncoll][ntemp]
+};
+
+struct Molecule {
+    int nlev = 0, nline = 0;
+    double amass = 0;
+    std::vector<double> eterm, gstat;
+    std::vector<int> iupp, ilow;
+    std::vector<double> aeinst, spfreq, eup, xnu;
+    std::vector<Partner> parts;
+};
+
+// --- LAMDA reader: positional, as readdata_ [BIN 0x1cf90-0x1e338] ------------
+struct LineReader {
+    FILE *f;
+    std::vector<char> buf;
+    char *p = nullptr;
+    bool ok = true;
+    explicit LineReader(FILE *ff) : f(ff), buf(1 << 16) {}
+    bool next() {
+        if (!fgets(buf.data(), (int)buf.size(), f)) { ok = false; return false; }
+        p = buf.data();
+        return true;
+    }
+    double real() {   // Fortran list-directed: blanks/commas separate, D exponents allowed
+        while (*p && (isspace((unsigned char)*p) || *p == ',')) ++p;
+        char tmp[64];
+        int k = 0;
+        while (*p && !isspace((unsigned char)*p) && *p != ',' && k < 63) {
+            char ch = *p++;
+            tmp[k++] = (ch == 'd' || ch == 'D') ? 'e' : ch;
+        }
+        tmp[k] = 0;
+        if (!k) { ok = false; return 0.0; }
+        char *end;
+        double v = strtod(tmp, &end);
+        if (*end) ok = false;
+        return v;
+    }
+    int integer() { return (int)real(); }
+};
+
+int load_lamda(const char *path, Molecule &m, std::string &err)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) { err = std::string("cannot open molecular data file: ") + path; return RX_E_IO; }
+    LineReader r(f);
+    auto fail = [&](const char *what) { fclose(f); err = std::string("malformed LAMDA file (") + what + "): " + path; return RX_E_IO; };
+    r.next(); r.next(); r.next();
+    if (!r.next()) return fail("weight");
+    m.amass = r.real();
+    r.next();
+    if (!r.next()) return fail("nlev");
+    m.nlev = r.integer();
+    if (!r.ok || m.nlev < 2 || m.nlev > 2999) return fail("nlev");
+    m.eterm.resize(m.nlev); m.gstat.resize(m.nlev);
+    r.next();
+    for (int i = 0; i < m.nlev; ++i) {
+        if (!r.next()) return fail("levels");
+        (void)r.real(); m.eterm[i] = r.real(); m.gstat[i] = r.real();
+    }
+    r.next();
+    if (!r.next()) return fail("nline");
+    m.nline = r.integer();
+    if (!r.ok || m.nline < 1 || m.nline > 99999) return fail("nline");
+    m.iupp.resize(m.nline); m.ilow.resize(m.nline); m.aeinst.resize(m.nline);
+    m.spfreq.resize(m.nline); m.eup.resize(m.nline); m.xnu.resize(m.nline);
+    r.next();
+    for (int l = 0; l < m.nline; ++l) {
+        if (!r.next()) return fail("lines");
+        (void)r.real();
+        m.iupp[l] = r.integer(); m.ilow[l] = r.integer();
+        m.aeinst[l] = r.real(); m.spfreq[l] = r.real(); m.eup[l] = r.real();
+        if (!r.ok || m.iupp[l] < 1 || m.iupp[l] > m.nlev || m.ilow[l] < 1 || m.ilow[l] > m.nlev)
+            return fail("line indices");
+        // xnu = eterm(iupp) - eterm(ilow), not the listed frequency [BIN 0x1d735-0x1d745]
+        m.xnu[l] = m.eterm[m.iupp[l] - 1] - m.eterm[m.ilow[l] - 1];
+        if (m.xnu[l] < 1e-30) return fail("illegal line frequency");
+    }
+    r.next();
+    if (!r.next()) return fail("npart");
+    int npart = r.integer();
+    if (!r.ok || npart < 1 || npart > RXK_MAXPART) return fail("npart");
+    m.parts.resize(npart);
+    for (int ip = 0; ip < npart; ++ip) {
+        Partner &P = m.parts[ip];
+        r.next();
+        if (!r.next()) return fail("partner id");
+        P.id = r.integer();
+        if (!r.ok || P.id < 1 || P.id > RXK_MAXPART) return fail("partner id");
+        r.next(); if (!r.next()) return fail("ncoll");
+        P.ncoll = r.integer();
+        r.next(); if (!r.next()) return fail("ntemp");
+        P.ntemp = r.integer();
+        if (!r.ok || P.ncoll < 1 || P.ntemp < 1) return fail("ncoll/ntemp");
+        P.temps.resize(P.ntemp); P.lcu.resize(P.ncoll); P.lcl.resize(P.ncoll);
+        P.coll.resize((size_t)P.ncoll * P.ntemp);
+        r.next(); if (!r.next()) return fail("temps");
+        for (int t = 0; t < P.ntemp; ++t) P.temps[t] = r.real();
+        r.next();
+        for (int c = 0; c < P.ncoll; ++c) {
+            if (!r.next()) return fail("rates");
+            (void)r.real();
+            P.lcu[c] = r.integer(); P.lcl[c] = r.integer();
+            for (int t = 0; t < P.ntemp; ++t) P.coll[(size_t)c * P.ntemp + t] = r.real();
+            if (!r.ok || P.lcu[c] < 1 || P.lcu[c] > m.nlev || P.lcl[c] < 1 || P.lcl[c] > m.nlev)
+                return fail("rate indices");
+        }
+    }
+    fclose(f);
+    return 0;
+}
+
+int pick_nl(int nlev)
+{
+    static const int sizes[] = {RX_NL_LIST};
+    for (int s : sizes) if (s >= nlev) return s;
+    return -1;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t reserve(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc(&p, want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct rx_handle {
+    int device = 0;
+    int method = 2;
+    double deltav_kms = 1.0;
+    double fortho = 0.75;
+    int miniter = 10, maxiter = 200;
+    Molecule mol;
+    int NL = 0;
+    int h2_total = 0;
+    std::vector<int> order;          // partner slots sorted by id
+    std::string err;
+    std::string kname;
+    // device tables
+    void *d_blob = nullptr;          // eterm, gstat, lines, inc, temps
+    std::vector<double *> d_ksym;
+    RxMolDev dmol{};
+    RxSourceDev *d_srcs = nullptr;
+    std::vector<RxSourceDev> h_srcs;
+    unsigned int *d_queue = nullptr;
+    int num_cu = 256, blocks_per_cu = 1;
+    // staging for the host-pointer API + 2-component scratch
+    DevBuf<double> s_params, s_lnp, s_flux, s_cflux, s_in3, s_dens, s_xpop, s_tex, s_tau, s_sb;
+    DevBuf<int32_t> s_src, s_status, s_niter, s_cstatus, s_cniter;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int hip_fail(rx_handle *h, hipError_t e, const char *what)
+{
+    h->err = std::string(what) + ": " + hipGetErrorString(e);
+    return RX_E_HIP;
+}
+#define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
+
+typedef void (*kernel_fn)(const RxKArgs);
+typedef void (*lukernel_fn)(const double *, double *, int, int);
+
+lukernel_fn lukernel_for(int NL)
+{
+    switch (NL) {
+#define RX_CASE(n) case n: return rxk::rx_lubksb_kernel<n>;
+        RX_NL_CASES
+#undef RX_CASE
+    }
+    return nullptr;
+}
+
+kernel_fn kernel_for(int NL)
+{
+    switch (NL) {
+#define RX_CASE(n) case n: return rxk::rx_solve_kernel<n>;
+        RX_NL_CASES
+#undef RX_CASE
+    }
+    return nullptr;
+}
+
+int build_tables(rx_handle *h)
+{
+    const Molecule &m = h->mol;
+    const int NL = h->NL;
+    // partner order = ascending id (accumulation order of readdata_, [BIN 0x1eaf9-0x1f378])
+    h->order.resize(m.parts.size());
+    for (size_t i = 0; i < m.parts.size(); ++i) h->order[i] = (int)i;
+    std::stable_sort(h->order.begin(), h->order.end(),
+                     [&](int x, int y) { return m.parts[x].id < m.parts[y].id; });
+    h->h2_total = 0;
+    for (const Partner &P : m.parts) if (P.id == 1) h->h2_total = 1;
+
+    RxLevTab LV;
+    for (int i = 0; i < RXK_MAXLEV; ++i) { LV.eterm[i] = 0.0; LV.gstat[i] = 1.0; }
+    for (int i = 0; i < m.nlev; ++i) { LV.eterm[i] = m.eterm[i]; LV.gstat[i] = m.gstat[i]; }
+    RxLineTab LT;
+    memset(&LT, 0, sizeof LT);
+    for (int l = 0; l < RXK_MAXLINES; ++l) { LT.gm[l] = LT.gn[l] = 1.0; LT.aein[l] = 1.0; LT.fgxta[l] = 1.0; LT.thcxt[l] = 1.0; }
+    for (int l = 0; l < m.nline; ++l) {
+        const int mu = m.iupp[l] - 1, nl_ = m.ilow[l] - 1;
+        const double A = m.aeinst[l], gm = m.gstat[mu], gn = m.gstat[nl_];
+        const double xnu = m.xnu[l];
+        const double xt = pow(xnu, 3.0);                  // xnu**3. -> pow() [BIN 0x19a71]
+        LT.m[l] = mu; LT.n[l] = nl_;
+        LT.aein[l] = A; LT.gm[l] = gm; LT.gn[l] = gn;
+        LT.agmgn[l] = A * (gm / gn);
+        LT.fgxta[l] = H_FGAUS * xt / A;
+        LT.thcxt[l] = xt * H_THC;
+        LT.fkxnu[l] = H_FK * xnu;
+        LT.thcxt_py[l] = H_THC_PY * xt;
+        LT.fkxnu_py[l] = H_FK_PY * xnu;
+    }
+    RxIncTab IT;
+    memset(&IT, 0, sizeof IT);
+    int e = 0;
+    for (int i = 0; i < RXK_MAXLEV; ++i) {
+        IT.rowptr[i] = e;
+        if (i < m.nlev)
+            for (int l = 0; l < m.nline; ++l) {          // line order = accumulation order of matrix_
+                if (m.iupp[l] - 1 == i) IT.ent[e++] = l | ((m.ilow[l] - 1) << 8) | (1 << 16);
+                else if (m.ilow[l] - 1 == i) IT.ent[e++] = l | ((m.iupp[l] - 1) << 8);
+            }
+    }
+    IT.rowptr[RXK_MAXLEV] = e;
+
+    size_t off_e = 0;
+    size_t off_l = (off_e + sizeof(RxLevTab) + 15) & ~size_t(15);
+    size_t off_i = off_l + sizeof(RxLineTab);
+    size_t off_t = (off_i + sizeof(RxIncTab) + 15) & ~size_t(15);
+    size_t total = off_t;
+    std::vector<size_t> off_temps;
+    for (int s : h->order) { off_temps.push_back(total); total += m.parts[s].ntemp * sizeof(double); }
+    std::vector<char> blob(total, 0);
+    memcpy(blob.data() + off_e, &LV, sizeof LV);
+    memcpy(blob.data() + off_l, &LT, sizeof LT);
+    memcpy(blob.data() + off_i, &IT, sizeof IT);
+    for (size_t q = 0; q < h->order.size(); ++q)
+        memcpy(blob.data() + off_temps[q], m.parts[h->order[q]].temps.data(),
+               m.parts[h->order[q]].ntemp * sizeof(double));
+    HIPCHK(h, hipMalloc(&h->d_blob, total));
+    HIPCHK(h, hipMemcpy(h->d_blob, blob.data(), total, hipMemcpyHostToDevice));
+
+    RxMolDev &D = h->dmol;
+    memset(&D, 0, sizeof D);
+    D.nlev = m.nlev; D.nline = m.nline; D.npart = (int)m.parts.size();
+    char *base = (char *)h->d_blob;
+    D.levels = (const RxLevTab *)(base + off_e);
+    D.lines = (const RxLineTab *)(base + off_l);
+    D.inc = (const RxIncTab *)(base + off_i);
+    for (size_t q = 0; q < h->order.size(); ++q) {
+        const Partner &P = m.parts[h->order[q]];
+        D.pid[q] = P.id; D.ntemp[q] = P.ntemp;
+        D.temps[q] = (const double *)(base + off_temps[q]);
+        // dense symmetric table [ntemp][NL][NL]
+        std::vector<double> K((size_t)P.ntemp * NL * NL, 0.0);
+        for (int c = 0; c < P.ncoll; ++c) {
+            const int u = P.lcu[c] - 1, l = P.lcl[c] - 1;
+            for (int t = 0; t < P.ntemp; ++t) {
+                const double v = P.coll[(size_t)c * P.ntemp + t];
+                K[((size_t)t * NL + u) * NL + l] += v;      // duplicates accumulate like crate(up,low) +=
+                K[((size_t)t * NL + l) * NL + u] = K[((size_t)t * NL + u) * NL + l];
+            }
+        }
+        double *dK = nullptr;
+        HIPCHK(h, hipMalloc(&dK, K.size() * sizeof(double)));
+        HIPCHK(h, hipMemcpy(dK, K.data(), K.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->d_ksym.push_back(dK);
+        D.ksym[q] = dK;
+    }
+    return 0;
+}
+
+int validate_molecule(rx_handle *h)
+{
+    const Molecule &m = h->mol;
+    if (m.nlev > RX_MAX_LEVELS || m.nline > RX_MAX_LINES) {
+        h->err = "molecule exceeds kernel limits (nlev<=64, nline<=64): one level per lane of a wavefront";
+        return RX_E_UNSUPP;
+    }
+    for (const Partner &P : m.parts)
+        for (int c = 0; c < P.ncoll; ++c) {
+            const double eu = m.eterm[P.lcu[c] - 1], el = m.eterm[P.lcl[c] - 1];
+            if (!(eu > el)) {
+                h->err = "collisional transition with E_up <= E_low is not supported by the dense rate table";
+                return RX_E_UNSUPP;
+            }
+            for (int t = 0; t < P.ntemp; ++t)
+                if (P.coll[(size_t)c * P.ntemp + t] < 0.0) { h->err = "negative collision rate"; return RX_E_IO; }
+        }
+    for (size_t a = 0; a < m.parts.size(); ++a)
+        for (size_t b = a + 1; b < m.parts.size(); ++b)
+            if (m.parts[a].id == m.parts[b].id) { h->err = "duplicate collision partner id"; return RX_E_UNSUPP; }
+    // two lines between the same pair of levels would need read-modify-write in Phase B
+    for (int l = 0; l < m.nline; ++l)
+        for (int k = l + 1; k < m.nline; ++k)
+            if ((m.iupp[l] == m.iupp[k] && m.ilow[l] == m.ilow[k]) ||
+                (m.iupp[l] == m.ilow[k] && m.ilow[l] == m.iupp[k])) {
+                h->err = "two radiative transitions between the same pair of levels";
+                return RX_E_UNSUPP;
+            }
+    return 0;
+}
+
+int fill_args(rx_handle *h, RxKArgs &a, int N, int ncomp, int mode)
+{
+    memset(&a, 0, sizeof a);
+    a.mol = h->dmol;
+    a.srcs = h->d_srcs;
+    a.N = N; a.ncomp = ncomp; a.mode = mode; a.method = h->method;
+    a.miniter = h->miniter; a.maxiter = h->maxiter; a.h2_total = h->h2_total;
+    a.deltav_cms = h->deltav_kms * 1e5;      // core.py:447-454: km/s -> cm/s
+    a.fortho = h->fortho;
+    a.queue = h->d_queue;
+    return 0;
+}
+
+int launch(rx_handle *h, const RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+{
+    if (a.N <= 0) return 0;
+    const int ncomp = (a.mode == RXK_MODE_SOLVE) ? 1 : a.ncomp;
+    const long items = (long)a.N * ncomp;
+    long blocks = (items + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK;
+    const long cap = (long)h->num_cu * h->blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    kernel_fn k = kernel_for(h->NL);
+    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
+    if (e0) HIPCHK(h, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, a);
+    if (ncomp == 2) {
+        const int tb = 256;
+        hipLaunchKernelGGL(rxk::rx_combine_kernel, dim3((a.N + tb - 1) / tb), dim3(tb), 0, st, a);
+    }
+    if (e1) HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int ensure_comp_scratch(rx_handle *h, RxKArgs &a, int N, int ncomp)
+{
+    if (ncomp != 2) return 0;
+    HIPCHK(h, h->s_cflux.reserve((size_t)N * ncomp * RXK_MAXNJ));
+    HIPCHK(h, h->s_cstatus.reserve((size_t)N * ncomp));
+    HIPCHK(h, h->s_cniter.reserve((size_t)N * ncomp));
+    a.comp_flux = h->s_cflux.p; a.comp_status = h->s_cstatus.p; a.comp_niter = h->s_cniter.p;
+    return 0;
+}
+
+int source_ncomp(rx_handle *h, const int32_t *src_index_host, int N, int src_fixed, int *ncomp_out)
+{
+    int nc = -1;
+    auto chk = [&](int s) -> int {
+        if (s < 0 || s >= RX_MAX_SOURCES || !h->h_srcs[s].set) { h->err = "source slot not set"; return RX_E_STATE; }
+        if (nc < 0) nc = h->h_srcs[s].ncomp;
+        else if (nc != h->h_srcs[s].ncomp) { h->err = "sources of one batch must share ncomp"; return RX_E_ARG; }
+        return 0;
+    };
+    if (!src_index_host) { int rc = chk(src_fixed); if (rc) return rc; }
+    else for (int i = 0; i < N; ++i) { int rc = chk(src_index_host[i]); if (rc) return rc; }
+    *ncomp_out = nc;
+    return 0;
+}
+
+}  // namespace
+
+// ============================ extern "C" ABI ==================================
+extern "C" {
+
+int rx_abi_version(void) { return RX_ABI_VERSION; }
+
+rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int device,
+                     char *err, size_t errlen)
+{
+    auto seterr = [&](const std::string &s) { if (err && errlen) { strncpy(err, s.c_str(), errlen - 1); err[errlen - 1] = 0; } };
+    if (!lamda_path || method < 1 || method > 3 || !(deltav_kms > 0) || device < 0) { seterr("bad argument"); return nullptr; }
+    rx_handle *h = new rx_handle;
+    h->device = device; h->method = method; h->deltav_kms = deltav_kms;
+    int rc = load_lamda(lamda_path, h->mol, h->err);
+    if (!rc) rc = validate_molecule(h);
+    if (!rc) { h->NL = pick_nl(h->mol.nlev); if (h->NL < 0) { h->err = "no kernel instantiation for this nlev"; rc = RX_E_UNSUPP; } }
+    if (rc) { seterr(h->err); delete h; return nullptr; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= device) {
+        seterr("no usable HIP device (libradex_emcee_amd has no CPU fallback)");
+        delete h; return nullptr;
+    }
+    auto hipfail = [&](const char *what, hipError_t ee) { seterr(std::string(what) + ": " + hipGetErrorString(ee)); rx_destroy(h); return (rx_handle *)nullptr; };
+    if ((e = hipSetDevice(device)) != hipSuccess) return hipfail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hipfail("hipGetDeviceProperties", e);
+    h->num_cu = prop.multiProcessorCount;
+    if (build_tables(h)) { seterr(h->err); rx_destroy(h); return nullptr; }
+    h->h_srcs.resize(RX_MAX_SOURCES);
+    for (auto &s : h->h_srcs) memset(&s, 0, sizeof s);
+    if ((e = hipMalloc(&h->d_srcs, sizeof(RxSourceDev) * RX_MAX_SOURCES)) != hipSuccess) return hipfail("hipMalloc", e);
+    if ((e = hipMemset(h->d_srcs, 0, sizeof(RxSourceDev) * RX_MAX_SOURCES)) != hipSuccess) return hipfail("hipMemset", e);
+    if ((e = hipMalloc(&h->d_queue, sizeof(unsigned int))) != hipSuccess) return hipfail("hipMalloc", e);
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return hipfail("hipEventCreate", e);
+    if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
+    int nb = 0;
+    kernel_fn k = kernel_for(h->NL);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
+        h->blocks_per_cu = std::min(nb, 2);
+    char nm[64];
+    snprintf(nm, sizeof nm, "rx_solve_kernel<%d>", h->NL);
+    h->kname = nm;
+    return h;
+}
+
+void rx_destroy(rx_handle *h)
+{
+    if (!h) return;
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    for (double *p : h->d_ksym) (void)hipFree(p);
+    if (h->d_srcs) (void)hipFree(h->d_srcs);
+    if (h->d_queue) (void)hipFree(h->d_queue);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    h->s_params.release(); h->s_lnp.release(); h->s_flux.release(); h->s_cflux.release();
+    h->s_in3.release(); h->s_dens.release(); h->s_xpop.release(); h->s_tex.release();
+    h->s_tau.release(); h->s_sb.release(); h->s_src.release(); h->s_status.release();
+    h->s_niter.release(); h->s_cstatus.release(); h->s_cniter.release();
+    delete h;
+}
+
+const char *rx_last_error(const rx_handle *h) { return h ? h->err.c_str() : "null handle"; }
+int rx_nlev(const rx_handle *h) { return h ? h->mol.nlev : RX_E_ARG; }
+int rx_nline(const rx_handle *h) { return h ? h->mol.nline : RX_E_ARG; }
+int rx_npart(const rx_handle *h) { return h ? (int)h->mol.parts.size() : RX_E_ARG; }
+const char *rx_kernel_name(const rx_handle *h) { return h ? h->kname.c_str() : ""; }
+
+int rx_partner_ids(const rx_handle *h, int32_t *out)
+{
+    if (!h || !out) return RX_E_ARG;
+    for (size_t i = 0; i < h->mol.parts.size(); ++i) out[i] = h->mol.parts[i].id;
+    return 0;
+}
+
+int rx_line_data(const rx_handle *h, double *xnu, double *spfreq, int32_t *iupp, int32_t *ilow)
+{
+    if (!h) return RX_E_ARG;
+    for (int l = 0; l < h->mol.nline; ++l) {
+        if (xnu) xnu[l] = h->mol.xnu[l];
+        if (spfreq) spfreq[l] = h->mol.spfreq[l];
+        if (iupp) iupp[l] = h->mol.iupp[l];
+        if (ilow) ilow[l] = h->mol.ilow[l];
+    }
+    return 0;
+}
+
+int rx_set_fortho(rx_handle *h, double fortho)
+{
+    if (!h || !(fortho >= 0.0 && fortho <= 1.0)) return RX_E_ARG;
+    h->fortho = fortho;
+    return 0;
+}
+
+int rx_set_iteration_limits(rx_handle *h, int miniter, int maxiter)
+{
+    if (!h || miniter < 0 || maxiter < 1) return RX_E_ARG;
+    h->miniter = miniter; h->maxiter = maxiter;
+    return 0;
+}
+
+int rx_set_source(rx_handle *h, int src, double tbg, int nJ, const int32_t *Jup, const double *flux,
+                  const double *eflux, const double *bounds, int ncomp, double T_d)
+{
+    if (!h) return RX_E_ARG;
+    if (src < 0 || src >= RX_MAX_SOURCES || nJ < 0 || nJ > RX_MAX_NJ || (ncomp != 1 && ncomp != 2) ||
+        (nJ > 0 && (!Jup || !flux || !eflux)) || !bounds) { h->err = "rx_set_source: bad argument"; return RX_E_ARG; }
+    if (!(tbg > 0.0)) { h->err = "rx_set_source: tbg must be > 0 (tbg<=0 selects RADEX's user-file/galactic backgrounds, out of scope)"; return RX_E_ARG; }
+    RxSourceDev S;
+    memset(&S, 0, sizeof S);
+    S.tbg = tbg; S.T_d = T_d; S.nJ = nJ; S.ncomp = ncomp; S.set = 1; S.data_ok = 1;
+    double logsum = 0.0;
+    for (int j = 0; j < nJ; ++j) {
+        if (Jup[j] < 1 || Jup[j] > h->mol.nline) { h->err = "rx_set_source: Jup outside the molecule's line list"; return RX_E_ARG; }
+        S.jidx[j] = Jup[j] - 1;
+        S.flux[j] = flux[j];
+        double e = fabs(eflux[j]);                       // np.maximum(np.abs(eflux), 1e-12)
+        if (!(e > 1e-12)) e = std::isnan(e) ? e : 1e-12;
+        S.esig[j] = e;
+        if (!std::isfinite(flux[j]) || !std::isfinite(e)) S.data_ok = 0;   // emcee_radex.py:144,149
+        logsum += log(e);
+    }
+    S.logterm2 = 2.0 * logsum;                           // 2*sum(log e), emcee_radex.py:165
+    for (int k = 0; k < 4 * ncomp; ++k) { S.bounds[k][0] = bounds[2 * k]; S.bounds[k][1] = bounds[2 * k + 1]; }
+    // backrad_, tbg > 0 branch [BIN 0x1be30-0x1c390]
+    for (int l = 0; l < h->mol.nline; ++l) {
+        const double x = h->mol.xnu[l];
+        const double hh = H_FK * x / tbg;
+        S.backi[l] = (hh >= 160.0) ? H_SEED_F : H_THC * pow(x, 3.0) / (exp(hh) - 1.0);
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->d_srcs + src, &S, sizeof S, hipMemcpyHostToDevice));
+    h->h_srcs[src] = S;
+    return 0;
+}
+
+int rx_lnprob_batch_device(rx_handle *h, int N, const double *d_params, const int32_t *d_src_index,
+                           double *d_lnp, int32_t *d_status, int32_t *d_niter, void *stream)
+{
+    if (!h || N < 0 || (N > 0 && (!d_params || !d_lnp))) return RX_E_ARG;
+    // with a device-side index the ncomp of slot 0 defines the batch layout
+    int ncomp = 0;
+    { int rc = source_ncomp(h, nullptr, N, 0, &ncomp); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    RxKArgs a;
+    fill_args(h, a, N, ncomp, RXK_MODE_LNPROB);
+    a.params = d_params; a.src_index = d_src_index; a.src_fixed = 0;
+    a.lnp = d_lnp; a.status = d_status; a.niter = d_niter;
+    { int rc = ensure_comp_scratch(h, a, N, ncomp); if (rc) return rc; }
+    return launch(h, a, (hipStream_t)stream);
+}
+
+int rx_lnprob_batch(rx_handle *h, int N, const double *params, const int32_t *src_index,
+                    double *lnp, int32_t *status, int32_t *niter)
+{
+    if (!h || N < 0 || (N > 0 && (!params || !lnp))) return RX_E_ARG;
+    if (N == 0) return 0;
+    int ncomp = 0;
+    { int rc = source_ncomp(h, src_index, N, 0, &ncomp); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t np = (size_t)N * 4 * ncomp;
+    HIPCHK(h, h->s_params.reserve(np));
+    HIPCHK(h, h->s_lnp.reserve(N));
+    HIPCHK(h, h->s_status.reserve(N));
+    HIPCHK(h, h->s_niter.reserve(N));
+    HIPCHK(h, hipMemcpy(h->s_params.p, params, np * sizeof(double), hipMemcpyHostToDevice));
+    const int32_t *dsrc = nullptr;
+    if (src_index) {
+        HIPCHK(h, h->s_src.reserve(N));
+        HIPCHK(h, hipMemcpy(h->s_src.p, src_index, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
+        dsrc = h->s_src.p;
+    }
+    RxKArgs a;
+    fill_args(h, a, N, ncomp, RXK_MODE_LNPROB);
+    a.params = h->s_params.p; a.src_index = dsrc; a.src_fixed = 0;
+    a.lnp = h->s_lnp.p; a.status = h->s_status.p; a.niter = h->s_niter.p;
+    { int rc = ensure_comp_scratch(h, a, N, ncomp); if (rc) return rc; }
+    { int rc = launch(h, a, nullptr); if (rc) return rc; }
+    HIPCHK(h, hipMemcpy(lnp, h->s_lnp.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) HIPCHK(h, hipMemcpy(status, h->s_status.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (niter) HIPCHK(h, hipMemcpy(niter, h->s_niter.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rx_model_flux_batch_device(rx_handle *h, int src, int N, const double *d_params, double *d_flux_out,
+                               int32_t *d_status, int32_t *d_niter, void *stream)
+{
+    if (!h || N < 0 || (N > 0 && (!d_params || !d_flux_out))) return RX_E_ARG;
+    int ncomp = 0;
+    { int rc = source_ncomp(h, nullptr, N, src, &ncomp); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    RxKArgs a;
+    fill_args(h, a, N, ncomp, RXK_MODE_FLUX);
+    a.params = d_params; a.src_fixed = src;
+    a.flux = d_flux_out; a.status = d_status; a.niter = d_niter;
+    { int rc = ensure_comp_scratch(h, a, N, ncomp); if (rc) return rc; }
+    return launch(h, a, (hipStream_t)stream);
+}
+
+int rx_model_flux_batch(rx_handle *h, int src, int N, const double *params, double *flux_out,
+                        int32_t *status, int32_t *niter)
+{
+    if (!h || N < 0 || (N > 0 && (!params || !flux_out))) return RX_E_ARG;
+    if (N == 0) return 0;
+    int ncomp = 0;
+    { int rc = source_ncomp(h, nullptr, N, src, &ncomp); if (rc) return rc; }
+    const int nJ = h->h_srcs[src].nJ;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t np = (size_t)N * 4 * ncomp;
+    HIPCHK(h, h->s_params.reserve(np));
+    HIPCHK(h, h->s_flux.reserve((size_t)N * std::max(nJ, 1)));
+    HIPCHK(h, h->s_status.reserve(N));
+    HIPCHK(h, h->s_niter.reserve(N));
+    HIPCHK(h, hipMemcpy(h->s_params.p, params, np * sizeof(double), hipMemcpyHostToDevice));
+    int rc = rx_model_flux_batch_device(h, src, N, h->s_params.p, h->s_flux.p, h->s_status.p, h->s_niter.p, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(flux_out, h->s_flux.p, (size_t)N * nJ * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) HIPCHK(h, hipMemcpy(status, h->s_status.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (niter) HIPCHK(h, hipMemcpy(niter, h->s_niter.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rx_solve_batch(rx_handle *h, int src, int N, const double *tkin, const double *cdmol,
+                   const double *dens, double *xpop, double *tex, double *tau, double *sb,
+                   int32_t *status, int32_t *niter)
+{
+    if (!h || N < 0 || (N > 0 && (!tkin || !cdmol || !dens))) return RX_E_ARG;
+    if (N == 0) return 0;
+    if (src < 0 || src >= RX_MAX_SOURCES || !h->h_srcs[src].set) { h->err = "source slot not set"; return RX_E_STATE; }
+    const int nlev = h->mol.nlev, nline = h->mol.nline, npart = (int)h->mol.parts.size();
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, h->s_in3.reserve((size_t)2 * N));
+    HIPCHK(h, h->s_dens.reserve((size_t)N * npart));
+    HIPCHK(h, h->s_xpop.reserve((size_t)N * nlev));
+    HIPCHK(h, h->s_tex.reserve((size_t)N * nline));
+    HIPCHK(h, h->s_tau.reserve((size_t)N * nline));
+    HIPCHK(h, h->s_sb.reserve((size_t)N * nline));
+    HIPCHK(h, h->s_status.reserve(N));
+    HIPCHK(h, h->s_niter.reserve(N));
+    HIPCHK(h, hipMemcpy(h->s_in3.p, tkin, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->s_in3.p + N, cdmol, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    // caller gives densities in file partner order; the kernel wants id order
+    std::vector<double> d2((size_t)N * npart);
+    for (int w = 0; w < N; ++w)
+        for (int q = 0; q < npart; ++q) d2[(size_t)w * npart + q] = dens[(size_t)w * npart + h->order[q]];
+    HIPCHK(h, hipMemcpy(h->s_dens.p, d2.data(), d2.size() * sizeof(double), hipMemcpyHostToDevice));
+    RxKArgs a;
+    fill_args(h, a, N, 1, RXK_MODE_SOLVE);
+    a.src_fixed = src;
+    a.tkin = h->s_in3.p; a.cdmol = h->s_in3.p + N; a.dens = h->s_dens.p;
+    a.xpop = h->s_xpop.p; a.tex = h->s_tex.p; a.tau = h->s_tau.p; a.sb = h->s_sb.p;
+    a.status = h->s_status.p; a.niter = h->s_niter.p;
+    { int rc = launch(h, a, nullptr); if (rc) return rc; }
+    if (xpop) HIPCHK(h, hipMemcpy(xpop, h->s_xpop.p, (size_t)N * nlev * sizeof(double), hipMemcpyDeviceToHost));
+    if (tex) HIPCHK(h, hipMemcpy(tex, h->s_tex.p, (size_t)N * nline * sizeof(double), hipMemcpyDeviceToHost));
+    if (tau) HIPCHK(h, hipMemcpy(tau, h->s_tau.p, (size_t)N * nline * sizeof(double), hipMemcpyDeviceToHost));
+    if (sb) HIPCHK(h, hipMemcpy(sb, h->s_sb.p, (size_t)N * nline * sizeof(double), hipMemcpyDeviceToHost));
+    if (status) HIPCHK(h, hipMemcpy(status, h->s_status.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (niter) HIPCHK(h, hipMemcpy(niter, h->s_niter.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x)
+{
+    if (!h || N < 0 || n < 2 || n > h->NL || (N > 0 && (!A || !x))) return RX_E_ARG;
+    if (N == 0) return 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, h->s_params.reserve((size_t)N * n * n));
+    HIPCHK(h, h->s_lnp.reserve((size_t)N * n));
+    HIPCHK(h, hipMemcpy(h->s_params.p, A, (size_t)N * n * n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(lukernel_for(h->NL), dim3(N), dim3(64), 0, nullptr, h->s_params.p, h->s_lnp.p, n, N);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpy(x, h->s_lnp.p, (size_t)N * n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rx_time_lnprob_device(rx_handle *h, int N, const double *d_params, const int32_t *d_src_index,
+                          double *d_lnp, int32_t *d_status, int32_t *d_niter, void *stream,
+                          int reps, double *ms_mean_out)
+{
+    if (!h || reps < 1 || !ms_mean_out) return RX_E_ARG;
+    int ncomp = 0;
+    { int rc = source_ncomp(h, nullptr, N, 0, &ncomp); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    RxKArgs a;
+    fill_args(h, a, N, ncomp, RXK_MODE_LNPROB);
+    a.params = d_params; a.src_index = d_src_index; a.src_fixed = 0;
+    a.lnp = d_lnp; a.status = d_status; a.niter = d_niter;
+    { int rc = ensure_comp_scratch(h, a, N, ncomp); if (rc) return rc; }
+    double sum = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        int rc = launch(h, a, (hipStream_t)stream, h->ev0, h->ev1);
+        if (rc) return rc;
+        HIPCHK(h, hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        sum += ms;
+    }
+    *ms_mean_out = sum / reps;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+"""Engine: thin Python owner of one rx_handle (one GPU).
+
+Mirrors what the reference keeps per pool worker -- one `pyradex.Radex` object
+created by `init_radex` [/root/reference/emcee/emcee_radex.py:104-117] plus the
+closure arguments of `lnprob` -- but evaluates whole walker batches per call.
+All numerics happen in libradex_emcee_amd.so (HIP, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .molecule import default_molfile
+
+METHODS = {"sphere": 1, "lvg": 2, "slab": 3}      # core.py:690-700
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Engine:
+    def __init__(self, molfile: str | None = None, species: str = "co", escapeProbGeom: str = "lvg",
+                 deltav: float = 1.0, device: int = 0):
+        self._L = _lib.load()
+        self._h = None
+        if escapeProbGeom not in METHODS:
+            raise ValueError("Invalid escapeProbGeom, must be one of " + ",".join(METHODS))
+        self.molfile = molfile or default_molfile(species)
+        err = C.create_string_buffer(512)
+        self._h = self._L.rx_create(self.molfile.encode(), METHODS[escapeProbGeom], float(deltav),
+                                    int(device), err, 512)
+        if not self._h:
+            raise EngineError("rx_create failed: " + err.value.decode())
+        self.device = int(device)
+        self.nlev = self._L.rx_nlev(self._h)
+        self.nline = self._L.rx_nline(self._h)
+        self.npart = self._L.rx_npart(self._h)
+        ids = np.zeros(self.npart, dtype=np.int32)
+        self._L.rx_partner_ids(self._h, _ip(ids))
+        self.partner_ids = [int(x) for x in ids]
+        self.xnu = np.zeros(self.nline)
+        self.spfreq = np.zeros(self.nline)
+        self.iupp = np.zeros(self.nline, dtype=np.int32)
+        self.ilow = np.zeros(self.nline, dtype=np.int32)
+        self._L.rx_line_data(self._h, _dp(self.xnu), _dp(self.spfreq), _ip(self.iupp), _ip(self.ilow))
+        self._sources = {}
+
+    # -- lifetime ---------------------------------------------------------------
+    def close(self):
+        if self._h:
+            self._L.rx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise EngineError("%s failed (rc=%d): %s" % (what, rc, self._L.rx_last_error(self._h).decode()))
+
+    @property
+    def kernel_name(self) -> str:
+        return self._L.rx_kernel_name(self._h).decode()
+
+    # -- configuration -----------------------------------------------------------
+    def set_fortho(self, fortho: float):
+        self._chk(self._L.rx_set_fortho(self._h, float(fortho)), "rx_set_fortho")
+
+    def set_iteration_limits(self, miniter=10, maxiter=200):
+        self._chk(self._L.rx_set_iteration_limits(self._h, int(miniter), int(maxiter)), "rx_set_iteration_limits")
+
+    def set_source(self, tbg, Jup=(), flux=(), eflux=(), bounds=None, ncomp=1, T_d=None, src=0):
+        Jup = np.ascontiguousarray(Jup, dtype=np.int32)
+        flux = np.ascontiguousarray(flux, dtype=np.float64)
+        eflux = np.ascontiguousarray(eflux, dtype=np.float64)
+        if bounds is None:
+            bounds = np.tile(np.array([[-np.inf, np.inf]]), (4 * ncomp, 1))
+        bounds = np.ascontiguousarray(bounds, dtype=np.float64).reshape(4 * ncomp, 2)
+        if not (len(Jup) == len(flux) == len(eflux)):
+            raise ValueError("Jup, flux, eflux must have equal lengths")
+        td = float("nan") if T_d is None else float(T_d)
+        rc = self._L.rx_set_source(self._h, int(src), float(tbg), len(Jup), _ip(Jup), _dp(flux), _dp(eflux),
+                                   _dp(bounds), int(ncomp), td)
+        self._chk(rc, "rx_set_source")
+        self._sources[int(src)] = dict(nJ=len(Jup), ncomp=int(ncomp))
+
+    # -- batched evaluation, host buffers --------------------------------------------
+    def lnprob_batch(self, params, src_index=None, return_info=False):
+        ncomp = self._sources[0]["ncomp"] if 0 in self._sources else 1
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4 * ncomp)
+        N = params.shape[0]
+        lnp = np.empty(N)
+        status = np.empty(N, dtype=np.int32)
+        niter = np.empty(N, dtype=np.int32)
+        si = None if src_index is None else np.ascontiguousarray(src_index, dtype=np.int32)
+        self._chk(self._L.rx_lnprob_batch(self._h, N, _dp(params), _ip(si), _dp(lnp), _ip(status), _ip(niter)),
+                  "rx_lnprob_batch")
+        return (lnp, status, niter) if return_info else lnp
+
+    def model_flux_batch(self, params, src=0, return_info=False):
+        info = self._sources[int(src)]
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4 * info["ncomp"])
+        N = params.shape[0]
+        flux = np.empty((N, info["nJ"]))
+        status = np.empty(N, dtype=np.int32)
+        niter = np.empty(N, dtype=np.int32)
+        self._chk(self._L.rx_model_flux_batch(self._h, int(src), N, _dp(params), _dp(flux), _ip(status), _ip(niter)),
+                  "rx_model_flux_batch")
+        return (flux, status, niter) if return_info else flux
+
+    def solve_batch(self, tkin, cdmol, dens, src=0):
+        """dens: [N, npart] in file partner order (see partner_ids)."""
+        tkin = np.ascontiguousarray(np.atleast_1d(tkin), dtype=np.float64)
+        cdmol = np.ascontiguousarray(np.atleast_1d(cdmol), dtype=np.float64)
+        N = tkin.shape[0]
+        dens = np.ascontiguousarray(dens, dtype=np.float64).reshape(N, self.npart)
+        out = dict(xpop=np.empty((N, self.nlev)), tex=np.empty((N, self.nline)),
+                   tau=np.empty((N, self.nline)), sb=np.empty((N, self.nline)),
+                   status=np.empty(N, dtype=np.int32), niter=np.empty(N, dtype=np.int32))
+        self._chk(self._L.rx_solve_batch(self._h, int(src), N, _dp(tkin), _dp(cdmol), _dp(dens), _dp(out["xpop"]),
+                                         _dp(out["tex"]), _dp(out["tau"]), _dp(out["sb"]), _ip(out["status"]),
+                                         _ip(out["niter"])), "rx_solve_batch")
+        return out
+
+    def lubksb_batch(self, A):
+        """A: [N, n, n]; returns x[N, n] (last row <- 1, rhs = e_last; see rx_lubksb_batch)."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        if A.ndim == 2:
+            A = A[None]
+        N, n, _ = A.shape
+        x = np.empty((N, n))
+        self._chk(self._L.rx_lubksb_batch(self._h, N, n, _dp(A), _dp(x)), "rx_lubksb_batch")
+        return x
+
+    # -- batched evaluation, device-resident torch tensors -------------------------------
+    def lnprob_batch_torch(self, params, lnp=None, status=None, niter=None, src_index=None, stream=None):
+        """params: CUDA float64 tensor [N, ndim] on this engine's device; asynchronous on `stream`."""
+        import torch
+        assert params.is_cuda and params.dtype == torch.float64 and params.is_contiguous()
+        N = params.shape[0]
+        dev = params.device
+        if lnp is None:
+            lnp = torch.empty(N, dtype=torch.float64, device=dev)
+        if status is None:
+            status = torch.empty(N, dtype=torch.int32, device=dev)
+        if niter is None:
+            niter = torch.empty(N, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        si = 0 if src_index is None else src_index.data_ptr()
+        self._chk(self._L.rx_lnprob_batch_device(self._h, N, params.data_ptr(), si, lnp.data_ptr(),
+                                                 status.data_ptr(), niter.data_ptr(), st), "rx_lnprob_batch_device")
+        return lnp, status, niter
+
+    def time_lnprob_torch(self, params, lnp, status, niter, reps=10, src_index=None, stream=None):
+        """Mean per-launch kernel time [ms] from HIP events recorded on the launch stream."""
+        import torch
+        st = torch.cuda.current_stream(params.device).cuda_stream if stream is None else stream
+        ms = C.c_double(0.0)
+        si = 0 if src_index is None else src_index.data_ptr()
+        self._chk(self._L.rx_time_lnprob_device(self._h, params.shape[0], params.data_ptr(), si, lnp.data_ptr(),
+                                                status.data_ptr(), niter.data_ptr(), st, int(reps),
+                                                C.byref(ms)), "rx_time_lnprob_device")
+        return ms.value

@@ -142,6 +142,9 @@ def main():
         ("co_synth", 3, 2.73, {2: 0.25e4, 3: 0.75e4}, 20.0, 1e16),             # slab
         ("co_synth", 2, 2.73, {2: 1e3, 3: 0.0}, 3000.5, 1e13),                 # T above table
         ("co_synth", 2, 2.73, {2: 1e3, 3: 2e3}, 1.5, 1e13),                    # T below table
+        # maser -> LVG escprob takes log of a negative number -> NaN in the rate matrix
+        ("co_synth", 2, 2.7315 * 3.5, {2: 0.25 * 10 ** 3.46750779, 3: 0.75 * 10 ** 3.46750779},
+         10 ** 2.46142043, 10 ** 18.73532281),
         ("toy6", 2, 2.73, {1: 1e4}, 25.0, 1e14),
         ("toy6", 2, 5.0, {1: 3e5}, 70.0, 1e17),
         ("toy6", 1, 2.73, {1: 1e3}, 10.0, 1e16),
