@@ -54,6 +54,13 @@ def load():
         raise EngineLibraryMissing(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  radex_emcee_amd has no CPU fallback." % LIB_PATH)
+    # PyTorch wheels bundle their own libamdhip64; whichever copy is loaded first serves the whole
+    # process.  Import torch first so that torch tensors/streams and this library share ONE HIP
+    # runtime (loading /opt/rocm's copy first leaves torch with "No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
     L.rx_abi_version.restype = C.c_int

@@ -1,8 +1,7 @@
 """Synthetic workloads of BASELINE.json / SURVEY.md section 8(d).
 
 Only shapes, bounds and seeds live here; model fluxes ("truth" SLEDs) are
-produced by whichever evaluator the caller passes in, so this module depends on
-neither the HIP engine nor the oracle.
+produced by whichever evaluator the caller passes in; this module evaluates nothing.
 """
 from __future__ import annotations
 

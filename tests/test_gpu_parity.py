@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP path (through the C ABI of libradex_emcee_amd.so) against
+(a) golden vectors computed by the reference's own radex.so and (b) the CPU oracle.
+
+Tolerances (north_star: flux within 1e-4 relative of reference RADEX):
+  * populations vs the reference binary: |dx| <= 1e-6*x + 1e-14 on every level (the
+    absolute term covers levels below ~1e-8 where the reference's own LU sits on its
+    round-off floor); Tex / tau: 1e-6 relative on lines whose two levels have x > 1e-8;
+  * fluxes vs the oracle: |df| <= 1e-4*|f| + 1e-10*F_bg, where
+    F_bg = max_l backi_l * size * 1e23 is the background flux through the source
+    solid angle: source_line_surfbrightness is `toti - backi`, so absolute errors
+    of order eps*backi are cancellation noise of the reference itself;
+  * iteration counts and status codes must be identical.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O                      # noqa: E402  (checker only)
+from radex_emcee_amd import workloads               # noqa: E402
+from radex_emcee_amd.engine import Engine           # noqa: E402
+
+FLUX_RTOL = 1e-4
+BG_FLOOR = 1e-10
+
+
+@pytest.fixture(scope="module")
+def engines(co_path):
+    return {m: Engine(co_path, escapeProbGeom=n) for m, n in ((1, "sphere"), (2, "lvg"), (3, "slab"))}
+
+
+@pytest.fixture(scope="module")
+def mol(co_path):
+    return O.Molecule(co_path)
+
+
+def _flux_ok(flux, ref, walkers, tbg, mol, ncomp=1):
+    st = O.State(mol)
+    st.backrad(tbg)
+    bmax = st.arr("backi").max()
+    size = np.zeros(len(walkers))
+    for c in range(ncomp):
+        size = np.maximum(size, 10.0 ** walkers[:, 4 * c + 3])
+    tol = FLUX_RTOL * np.abs(ref) + BG_FLOOR * (bmax * size * 1e23)[:, None]
+    d = np.abs(flux - ref)
+    both_nan = np.isnan(flux) & np.isnan(ref)
+    return (d <= tol) | both_nan, d
+
+
+def test_lubksb_vs_reference_binary(engines, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "ref_lubksb.json")))
+    for c in g["cases"]:
+        n = c["n"]
+        x = engines[2].lubksb_batch(np.array(c["A"]).reshape(n, n))[0]
+        want = np.array(c["x"])
+        assert np.max(np.abs(x - want) / np.abs(want)) < 1e-10, n
+
+
+def test_solve_vs_reference_binary(engines, golden_dir, toy_path):
+    g = json.load(open(os.path.join(golden_dir, "ref_matrix.json")))
+    toy = {m: Engine(toy_path, escapeProbGeom=n) for m, n in ((1, "sphere"), (2, "lvg"))}
+    worst = 0.0
+    for c in g["cases"]:
+        e = engines[c["method"]] if c["mol"] == "co_synth" else toy[c["method"]]
+        e.set_source(c["tbg"])
+        dens = [[c["density"].get(str(pid), 0.0) for pid in e.partner_ids]]
+        r = e.solve_batch([c["tkin"]], [c["cdmol"]], dens)
+        assert r["niter"][0] == c["niter"], (c["mol"], c["tkin"], r["niter"][0], c["niter"])
+        assert r["status"][0] == (0 if c["conv"] else 1)
+        x = np.array(c["xpop"])
+        # populations: 1e-6 relative; below ~1e-8 the reference's own LU sits on its round-off
+        # floor (absolute errors ~1e-16), hence the small absolute term
+        ex = np.abs(r["xpop"][0] - x)
+        assert np.all(ex <= 1e-6 * x + 1e-14), (c["mol"], c["method"], c["tkin"], np.max(ex / x))
+        big = x > 1e-8
+        dx = np.max(ex[big] / x[big])
+        iu, il = e.iupp - 1, e.ilow - 1
+        lines = (x[iu] > 1e-8) & (x[il] > 1e-8)
+        tex, tau = np.array(c["tex"]), np.array(c["taul"])
+        dt = np.max(np.abs(r["tex"][0][lines] - tex[lines]) / np.abs(tex[lines]))
+        dtau = np.max(np.abs(r["tau"][0][lines] - tau[lines]) / np.abs(tau[lines]))
+        worst = max(worst, dx, dt, dtau)
+        assert dx < 1e-6 and dt < 1e-6 and dtau < 1e-6, (c["mol"], c["method"], c["tkin"], dx, dt, dtau)
+    print("worst deviation from the reference binary: %.2e" % worst)
+
+
+def _truth_source(eng, mol, cfg):
+    src0 = O.Source(cfg["tbg"], cfg["Jup"], np.ones(len(cfg["Jup"])), np.ones(len(cfg["Jup"])),
+                    cfg["bounds"], cfg["ncomp"], cfg["T_d"])
+    truth_flux = O.model_flux_batch(mol, src0, cfg["truth"][None, :])[0][0]
+    eflux = 0.1 * truth_flux
+    eng.set_source(cfg["tbg"], cfg["Jup"], truth_flux, eflux, cfg["bounds"], cfg["ncomp"], cfg["T_d"])
+    return O.Source(cfg["tbg"], cfg["Jup"], truth_flux, eflux, cfg["bounds"], cfg["ncomp"], cfg["T_d"])
+
+
+def test_config2_flux_and_lnprob_vs_oracle(engines, mol):
+    """BASELINE config 2: 1024 walkers uniform in the prior box, J=1..10, 1 component."""
+    eng = engines[2]
+    cfg = workloads.config2(1024)
+    src = _truth_source(eng, mol, cfg)
+    flux, st, nit = eng.model_flux_batch(cfg["walkers"], return_info=True)
+    rf, rst, rnit = O.model_flux_batch(mol, src, cfg["walkers"], nthreads=8)
+    assert np.array_equal(st, rst)
+    assert (nit == rnit).mean() >= 0.995            # a convergence test may flip on the last bit
+    ok, d = _flux_ok(flux, rf, cfg["walkers"], cfg["tbg"], mol)
+    assert ok.all(), (np.argwhere(~ok)[:5], d[~ok][:5])
+    sig = np.abs(rf) > 1e-6 * np.max(np.abs(rf), axis=1, keepdims=True)
+    rel = d[sig] / np.abs(rf[sig])
+    assert np.median(rel) < 1e-12 and np.percentile(rel, 99) < 1e-6
+    # J-indexing: flux column j is line Jup[j]-1
+    assert (st == 1).sum() > 0 and (st == 0).sum() > 900
+
+    lnp, st2, nit2 = eng.lnprob_batch(cfg["walkers"], return_info=True)
+    rl, rst2, rnit2 = O.lnprob_batch(mol, src, cfg["walkers"], nthreads=8)
+    assert np.array_equal(st2, rst2)
+    fin = np.isfinite(rl)
+    assert np.array_equal(fin, np.isfinite(lnp))
+    assert np.all(lnp[~fin] == -np.inf)
+    rel = np.abs(lnp[fin] - rl[fin]) / np.maximum(np.abs(rl[fin]), 1.0)
+    assert rel.max() < 1e-6, rel.max()
+
+
+def test_prior_edges_invalid_and_floor(engines, mol):
+    eng = engines[2]
+    cfg = workloads.config2(8)
+    src = _truth_source(eng, mol, cfg)
+    b = cfg["bounds"]
+    mid = 0.5 * (b[:, 0] + b[:, 1])
+    P = np.tile(np.array([4.0, 1.8, 17.0, mid[3]]), (10, 1))
+    P[1, 0] = b[0, 1] + 1e-9                 # above the box
+    P[2, 1] = b[1, 0] - 1e-9                 # below the box
+    P[3] = [4.0, 1.8, 14.0 + 4.0, mid[3]]; P[3, 2] = P[3, 0] + 10.0      # p2-p0 == 10.0 -> -inf
+    P[4, 0], P[4, 2] = 2.0, 19.5             # p2-p0 == 17.5 -> -inf
+    P[5, 2] = np.nan                         # NaN passes the prior, dies in lnlike
+    P[6, 0] = b[0, 0]                        # exactly on the box edge is allowed
+    lnp, st, _ = eng.lnprob_batch(P, return_info=True)
+    rl, rst, _ = O.lnprob_batch(mol, src, P)
+    assert np.array_equal(st, rst), (st, rst)
+    assert np.array_equal(np.isfinite(lnp), np.isfinite(rl))
+    assert list(st[1:5]) == [3, 3, 3, 3] and st[5] == 2 and st[0] == 0 and st[6] in (0, 1)
+    # ValueError paths of the setters: T > 1e4 K, column > 1e25 (needs a wide box)
+    wide = np.array([[-8, 12.0], [-1, 6.0], [0.0, 30.0], [-30, 0.0]])
+    eng.set_source(cfg["tbg"], cfg["Jup"], src.flux, src.eflux, wide)
+    srcw = O.Source(cfg["tbg"], cfg["Jup"], src.flux, src.eflux, wide)
+    Q = np.array([[4.0, 4.5, 15.0, -10.0], [10.0, 2.0, 25.5, -10.0], [-6.0, 2.0, 4.9, -10.0], [4.0, 2.0, 16.0, -10.0]])
+    lnp, st, _ = eng.lnprob_batch(Q, return_info=True)
+    rl, rst, _ = O.lnprob_batch(mol, srcw, Q)
+    assert list(st) == [2, 2, 2, 0] and np.array_equal(st, rst)
+    flux, fst, _ = eng.model_flux_batch(Q, return_info=True)
+    assert np.isnan(flux[:3]).all() and np.isfinite(flux[3]).all()
+    # sigma floor: eflux = 0 -> e = 1e-12 (emcee_radex.py:147); non-finite data -> -inf everywhere
+    eng.set_source(cfg["tbg"], cfg["Jup"], src.flux, np.zeros(10), wide)
+    srcz = O.Source(cfg["tbg"], cfg["Jup"], src.flux, np.zeros(10), wide)
+    lnp = eng.lnprob_batch(Q[3:])
+    rl = O.lnprob_batch(mol, srcz, Q[3:])[0]
+    assert np.isfinite(lnp[0]) and abs(lnp[0] - rl[0]) <= 1e-6 * abs(rl[0])
+    bad = src.flux.copy(); bad[2] = np.nan
+    eng.set_source(cfg["tbg"], cfg["Jup"], bad, src.eflux, wide)
+    assert eng.lnprob_batch(Q[3:])[0] == -np.inf
+
+
+def test_two_component_vs_oracle(engines, mol):
+    eng = engines[2]
+    cfg = workloads.config4(256)
+    src = _truth_source(eng, mol, cfg)
+    W = cfg["walkers"].copy()
+    W[5, 5] = W[5, 1] - 0.01         # T2 <= T1            -> -inf
+    W[6, 3] = W[6, 7] - 0.5          # size1 < size2       -> -inf
+    W[7, 2] = W[7, 0] + 18.0         # N1-n1 >= 18         -> -inf
+    lnp, st, nit = eng.lnprob_batch(W, return_info=True)
+    rl, rst, rnit = O.lnprob_batch(mol, src, W, nthreads=8)
+    assert np.array_equal(st, rst)
+    assert (nit == rnit).mean() > 0.99
+    fin = np.isfinite(rl)
+    assert np.array_equal(fin, np.isfinite(lnp)) and not fin[5] and not fin[6] and not fin[7]
+    rel = np.abs(lnp[fin] - rl[fin]) / np.maximum(np.abs(rl[fin]), 1.0)
+    assert rel.max() < 1e-6, rel.max()
+    flux = eng.model_flux_batch(cfg["walkers"][:64])
+    rf = O.model_flux_batch(mol, src, cfg["walkers"][:64])[0]
+    ok, d = _flux_ok(flux, rf, cfg["walkers"][:64], cfg["tbg"], mol, ncomp=2)
+    assert ok.all()
+    # T_d = None: flat prior on log T_cold too
+    eng.set_source(cfg["tbg"], cfg["Jup"], src.flux, src.eflux, cfg["bounds"], 2, None)
+    srcn = O.Source(cfg["tbg"], cfg["Jup"], src.flux, src.eflux, cfg["bounds"], 2, None)
+    a = eng.lnprob_batch(cfg["walkers"][:64])
+    b = O.lnprob_batch(mol, srcn, cfg["walkers"][:64])[0]
+    fin = np.isfinite(b)
+    assert fin.sum() > 10 and np.array_equal(fin, np.isfinite(a))
+    assert np.max(np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1.0)) < 1e-6
+
+
+def test_two_component_flux_is_sum_of_single_component_fluxes(engines, mol):
+    """emcee_radex_2comp.py:144-147: intensity = comp1 + comp2, bit-exact on the same kernel."""
+    eng = engines[2]
+    c2, c1 = workloads.config4(64), workloads.config2(4)
+    eng.set_source(c2["tbg"], c2["Jup"], np.ones(10), np.ones(10), c2["bounds"], 2, 40.0, src=0)
+    eng.set_source(c2["tbg"], c2["Jup"], np.ones(10), np.ones(10), c1["bounds"], 1, None, src=1)
+    f2 = eng.model_flux_batch(c2["walkers"], src=0)
+    fa = eng.model_flux_batch(c2["walkers"][:, :4].copy(), src=1)
+    fb = eng.model_flux_batch(c2["walkers"][:, 4:].copy(), src=1)
+    assert np.array_equal(f2, fa + fb)
+
+
+def test_multi_source_batch(engines, mol):
+    """BASELINE config 3 in miniature: several sources advanced by one launch."""
+    eng = engines[2]
+    zs, jups = [3.6345, 3.0413, 2.951], [[3, 4, 5, 6, 7], [1, 3, 5, 8, 10], [5]]
+    fl = [[5.699, 7.8, 9.734, 9.979, 7.962], [1.456, 7.008, 10.039, 9.3, 3.2], [9.89]]
+    ef = [[2.248, 1.5, 1.188, 1.672, 0.915], [0.463, 1.193, 4.17, 0.4, 0.2], [0.618]]
+    srcs, P, idx = [], [], []
+    for k, z in enumerate(zs):
+        b = workloads.bounds_1comp(z)
+        tbg = workloads.T_CMB0 * (1 + z)
+        eng.set_source(tbg, jups[k], fl[k], ef[k], b, src=k)
+        srcs.append(O.Source(tbg, jups[k], fl[k], ef[k], b))
+        P.append(workloads.draw_prior_1comp(b, 40, 100 + k))
+        idx += [k] * 40
+    P = np.concatenate(P)
+    idx = np.array(idx, dtype=np.int32)
+    perm = np.random.default_rng(5).permutation(len(P))
+    lnp = eng.lnprob_batch(P[perm], src_index=idx[perm])
+    ref = np.concatenate([O.lnprob_batch(mol, srcs[k], P[idx == k])[0] for k in range(3)])[perm]
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(lnp))
+    assert np.max(np.abs(lnp[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1.0)) < 1e-6
+
+
+def test_general_molecule_toy6(toy_path):
+    """Non-ladder line list, one 'H2' partner, 6 levels -> the NL=8 kernel instantiation."""
+    eng = Engine(toy_path)
+    mol = O.Molecule(toy_path)
+    assert eng.nlev == 6 and eng.nline == 7 and eng.partner_ids == [1]
+    b = np.array([[2.0, 7.0], [0.5, 2.4], [12.0, 18.0], [-12.0, -8.0]])
+    rng = np.random.default_rng(11)
+    P = b[:, 0] + (b[:, 1] - b[:, 0]) * rng.random((200, 4))
+    P[:, 2] = np.clip(P[:, 2], P[:, 0] + 10.01, P[:, 0] + 17.49)
+    P[:, 2] = np.clip(P[:, 2], 12.0, 18.0)
+    Jup = [1, 2, 3, 5, 7]
+    eng.set_source(2.73, Jup, np.ones(5), 0.3 * np.ones(5), b)
+    src = O.Source(2.73, Jup, np.ones(5), 0.3 * np.ones(5), b)
+    flux, st, nit = eng.model_flux_batch(P, return_info=True)
+    rf, rst, rnit = O.model_flux_batch(mol, src, P)
+    assert np.array_equal(st, rst) and (nit == rnit).mean() > 0.99
+    ok, d = _flux_ok(flux, rf, P, 2.73, mol)
+    assert ok.all()
+    lnp = eng.lnprob_batch(P)
+    rl = O.lnprob_batch(mol, src, P)[0]
+    fin = np.isfinite(rl)
+    assert np.array_equal(fin, np.isfinite(lnp))
+    assert np.max(np.abs(lnp[fin] - rl[fin]) / np.maximum(np.abs(rl[fin]), 1.0)) < 1e-6
+
+
+def test_full_size_properties(engines, mol):
+    """Size-independent properties at the stress size (65536 walkers)."""
+    import torch
+    eng = engines[2]
+    cfg = workloads.config2(65536, seed=5678)
+    _truth_source(eng, mol, cfg)
+    dev = torch.device("cuda:0")
+    P = torch.from_numpy(cfg["walkers"]).to(dev)
+    a, sa, na = eng.lnprob_batch_torch(P)
+    torch.cuda.synchronize()
+    b, sb, nb = eng.lnprob_batch_torch(P)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(sa, sb) and torch.equal(na, nb)       # deterministic
+    perm = torch.randperm(P.shape[0], device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    c, sc, nc = eng.lnprob_batch_torch(P[perm].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(c, a[perm]) and torch.equal(nc, na[perm])                   # order independent
+    sub, _, _ = eng.lnprob_batch_torch(P[1000:1512].contiguous())                  # batch-size independent
+    torch.cuda.synchronize()
+    assert torch.equal(sub, a[1000:1512])
+    an = a.cpu().numpy()
+    assert np.isfinite(an).mean() > 0.9 and (na >= 11).all() and (na <= 200).all()
+    # spot-check 256 of them against the oracle
+    pick = np.random.default_rng(9).choice(P.shape[0], 256, replace=False)
+    src = _truth_source(eng, mol, cfg)
+    rl = O.lnprob_batch(mol, src, cfg["walkers"][pick], nthreads=8)[0]
+    fin = np.isfinite(rl)
+    assert np.max(np.abs(an[pick][fin] - rl[fin]) / np.maximum(np.abs(rl[fin]), 1.0)) < 1e-6
+
+
+def test_device_pointer_api_on_side_stream(engines, mol):
+    import torch
+    eng = engines[2]
+    cfg = workloads.config2(512)
+    _truth_source(eng, mol, cfg)
+    dev = torch.device("cuda:0")
+    host = eng.lnprob_batch(cfg["walkers"])
+    s = torch.cuda.Stream(device=dev)
+    P = torch.from_numpy(cfg["walkers"]).to(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        lnp, st, nit = eng.lnprob_batch_torch(P, stream=s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(lnp.cpu().numpy(), host)
+    ms = eng.time_lnprob_torch(P, lnp, st, nit, reps=2)
+    assert 0.0 < ms < 1000.0
