@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradex_emcee_amd.so")
+LIB_PATH = os.environ.get("RADEX_EMCEE_AMD_LIB") or os.path.join(_HERE, "libradex_emcee_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 RX_OK, RX_MAXITER, RX_INVALID, RX_PRIOR = 0, 1, 2, 3

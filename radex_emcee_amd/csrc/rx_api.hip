@@ -194,7 +194,7 @@ struct rx_handle {
     RxSourceDev *d_srcs = nullptr;
     std::vector<RxSourceDev> h_srcs;
     unsigned int *d_queue = nullptr;
-    int num_cu = 256, blocks_per_cu = 1;
+    int num_cu = 256, blocks_per_cu2 = 1;
     // staging for the host-pointer API + 2-component scratch
     DevBuf<double> s_params, s_lnp, s_flux, s_cflux, s_in3, s_dens, s_xpop, s_tex, s_tau, s_sb;
     DevBuf<int32_t> s_src, s_status, s_niter, s_cstatus, s_cniter;
@@ -223,10 +223,10 @@ lukernel_fn lukernel_for(int NL)
     return nullptr;
 }
 
-kernel_fn kernel_for(int NL)
+kernel_fn kernel_for(int NL, int occ)
 {
     switch (NL) {
-#define RX_CASE(n) case n: return rxk::rx_solve_kernel<n>;
+#define RX_CASE(n) case n: return occ >= 2 ? rxk::rx_solve_kernel<n, 2> : rxk::rx_solve_kernel<n, 1>;
         RX_NL_CASES
 #undef RX_CASE
     }
@@ -375,10 +375,12 @@ int launch(rx_handle *h, const RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullp
     const int ncomp = (a.mode == RXK_MODE_SOLVE) ? 1 : a.ncomp;
     const long items = (long)a.N * ncomp;
     long blocks = (items + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK;
-    const long cap = (long)h->num_cu * h->blocks_per_cu;
+    // one wavefront per SIMD until the batch exceeds the chip, then the 2-wave/SIMD build
+    const int occ = (blocks > (long)h->num_cu && h->blocks_per_cu2 >= 2) ? 2 : 1;
+    const long cap = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    kernel_fn k = kernel_for(h->NL);
+    kernel_fn k = kernel_for(h->NL, occ);
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
     if (e0) HIPCHK(h, hipEventRecord(e0, st));
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, a);
@@ -454,11 +456,11 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
     int nb = 0;
-    kernel_fn k = kernel_for(h->NL);
+    kernel_fn k = kernel_for(h->NL, 2);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
-        h->blocks_per_cu = std::min(nb, 2);
+        h->blocks_per_cu2 = std::min(nb, 2);
     char nm[64];
-    snprintf(nm, sizeof nm, "rx_solve_kernel<%d>", h->NL);
+    snprintf(nm, sizeof nm, "rx_solve_kernel<%d, 1>", h->NL);
     h->kname = nm;
     return h;
 }
@@ -669,7 +671,19 @@ int rx_solve_batch(rx_handle *h, int src, int N, const double *tkin, const doubl
     a.tkin = h->s_in3.p; a.cdmol = h->s_in3.p + N; a.dens = h->s_dens.p;
     a.xpop = h->s_xpop.p; a.tex = h->s_tex.p; a.tau = h->s_tau.p; a.sb = h->s_sb.p;
     a.status = h->s_status.p; a.niter = h->s_niter.p;
+#ifdef RX_STAMPS
+    HIPCHK(h, h->s_cflux.reserve((size_t)N * 64));
+    a.comp_flux = h->s_cflux.p;
+#endif
     { int rc = launch(h, a, nullptr); if (rc) return rc; }
+#ifdef RX_STAMPS
+    if (getenv("RX_STAMP_FILE")) {
+        std::vector<double> d((size_t)N * 64);
+        HIPCHK(h, hipMemcpy(d.data(), h->s_cflux.p, d.size() * sizeof(double), hipMemcpyDeviceToHost));
+        FILE *f = fopen(getenv("RX_STAMP_FILE"), "wb");
+        if (f) { fwrite(d.data(), sizeof(double), d.size(), f); fclose(f); }
+    }
+#endif
     if (xpop) HIPCHK(h, hipMemcpy(xpop, h->s_xpop.p, (size_t)N * nlev * sizeof(double), hipMemcpyDeviceToHost));
     if (tex) HIPCHK(h, hipMemcpy(tex, h->s_tex.p, (size_t)N * nline * sizeof(double), hipMemcpyDeviceToHost));
     if (tau) HIPCHK(h, hipMemcpy(tau, h->s_tau.p, (size_t)N * nline * sizeof(double), hipMemcpyDeviceToHost));

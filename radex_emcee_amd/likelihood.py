@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference drivers' posterior functions, backed by the HIP engine.
+
+Per-walker API with the reference's names and argument meaning
+  [/root/reference/emcee/emcee_radex.py:98-181, emcee/emcee_radex_2comp.py:106-244]:
+    init_radex(tbg), model_lvg(Jup, params, R), lnlike(p, Jup, flux, eflux, R),
+    lnprior(p, bounds[, T_d]), lnprob(p, Jup, flux, eflux, bounds=[, T_d=])
+and the batched form the sampler uses (one kernel launch per half-step):
+    Posterior(...).lnprob_batch(P[N, ndim]) -> lnp[N]
+
+All numerics (prior, RADEX solve, chi^2) run in libradex_emcee_amd.so; these functions only
+marshal arguments.  `lnprior` is also available as pure host logic for bound checking in
+optimiser warm-starts.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import Engine
+
+opr = 3
+fortho = opr / (1 + opr)                 # emcee_radex.py:95-96
+
+R = None                                  # per-process engine handle, like the reference's global
+
+
+def init_radex(tbg=2.7315, molfile=None, device=0):
+    """emcee_radex.py:104-117: one handle per process/GPU."""
+    global R
+    if R is None:
+        R = Engine(molfile=molfile, species='co', escapeProbGeom='lvg', deltav=1.0, device=device)
+    R.set_source(tbg)
+    R._tbg = float(tbg)
+    return R
+
+
+class Posterior:
+    """Everything `lnprob` closes over for one source, resident on one GPU."""
+
+    def __init__(self, Jup, flux, eflux, bounds, tbg, ncomp=1, T_d=None, engine=None, src=0,
+                 molfile=None, device=0):
+        self.engine = engine or Engine(molfile=molfile, device=device)
+        self.ncomp, self.ndim, self.src = int(ncomp), 4 * int(ncomp), int(src)
+        self.Jup = np.asarray(np.int_(Jup))
+        self.flux = np.asarray(flux, dtype=np.float64)
+        self.eflux = np.asarray(eflux, dtype=np.float64)
+        self.bounds = np.asarray(bounds, dtype=np.float64).reshape(self.ndim, 2)
+        self.T_d = T_d
+        self.tbg = float(tbg)
+        self.engine.set_source(self.tbg, self.Jup, self.flux, self.eflux, self.bounds, self.ncomp,
+                               self.T_d, src=self.src)
+
+    def model_lvg(self, params):
+        """[N, ndim] -> [N, nJ] Jy km/s (NaN where the reference raises ValueError)."""
+        P = np.atleast_2d(np.asarray(params, dtype=np.float64))
+        return self.engine.model_flux_batch(P, src=self.src)
+
+    def lnprob_batch(self, params, return_info=False):
+        P = np.atleast_2d(np.asarray(params, dtype=np.float64))
+        if self.src == 0:
+            return self.engine.lnprob_batch(P, return_info=return_info)
+        idx = np.full(len(P), self.src, dtype=np.int32)
+        return self.engine.lnprob_batch(P, src_index=idx, return_info=return_info)
+
+    __call__ = lnprob_batch
+
+    def lnprob(self, p):
+        return float(self.lnprob_batch(np.asarray(p)[None, :])[0])
+
+
+# ---- per-walker functions with the reference's signatures ---------------------------------
+def model_lvg(Jup, params, R=None):
+    """emcee_radex.py:120-130 (4 params) / emcee_radex_2comp.py:122-147 (8 params).
+    Raises ValueError where the reference's setters do."""
+    R = R or globals()["R"]
+    p = np.asarray(params, dtype=np.float64)
+    ncomp = p.size // 4
+    Jup = np.asarray(np.int_(Jup))
+    wide = np.tile(np.array([-np.inf, np.inf]), (4 * ncomp, 1))
+    R.set_source(R._tbg, Jup, np.zeros(len(Jup)), np.ones(len(Jup)), wide, ncomp, None, src=0)
+    flux, status, _ = R.model_flux_batch(p[None, :], src=0, return_info=True)
+    if status[0] == 2:
+        raise ValueError("parameters outside RADEX's valid range (temperature/column/colliders)")
+    return flux[0]
+
+
+def lnprior(p, bounds, T_d=None, R=None):
+    """emcee_radex.py:169-175; emcee_radex_2comp.py:199-234 (host logic, no engine needed)."""
+    p = np.asarray(p, dtype=np.float64)
+    bounds = np.asarray(bounds, dtype=np.float64)
+    if np.any(p > bounds[:, 1]) or np.any(p < bounds[:, 0]):
+        return -np.inf
+    if p.size == 4:
+        if (p[2] - p[0] >= 17.5) or (p[2] - p[0] <= 10.0):
+            return -np.inf
+        return 0.0
+    if p[5] <= p[1]:
+        return -np.inf
+    if ((p[2] - p[0]) >= 18.0 or (p[2] - p[0]) <= 9.0 or (p[6] - p[4]) >= 18.0 or (p[6] - p[4]) <= 9.0):
+        return -np.inf
+    if p[3] < p[7]:
+        return -np.inf
+    logp = 0.0
+    for idx, (value, bound) in enumerate(zip(p, bounds)):
+        if idx == 1 and T_d is not None:
+            T_kin = 10.0 ** value
+            if T_d <= 0:
+                return -np.inf
+            sigma = 1.0 * T_d
+            logp += (-0.5 * ((T_kin - T_d) / sigma) ** 2.0 - np.log(sigma * np.sqrt(2.0 * np.pi)))
+        else:
+            logp += -(bound[1] - bound[0])
+    return logp
+
+
+def lnlike(p, Jup, flux, eflux, R=None, sigma_floor=1e-12):
+    """emcee_radex.py:132-167: Gaussian log-likelihood with the reference's guards."""
+    R = R or globals()["R"]
+    p = np.asarray(p, dtype=np.float64)
+    # the model comes from the GPU; chi^2 is formed on the host exactly as the reference does
+    try:
+        model_flux = model_lvg(Jup, p, R)
+    except ValueError:
+        return -np.inf
+    flux = np.asarray(flux, dtype=np.float64)
+    model_flux = np.asarray(model_flux, dtype=np.float64)
+    eflux = np.asarray(eflux, dtype=np.float64)
+    if not (np.all(np.isfinite(flux)) and np.all(np.isfinite(model_flux))):
+        return -np.inf
+    e = np.maximum(np.abs(eflux), sigma_floor)
+    if not np.all(np.isfinite(e)):
+        return -np.inf
+    with np.errstate(over='ignore', divide='ignore', invalid='ignore'):
+        r = (flux - model_flux) / e
+    if not np.all(np.isfinite(r)):
+        return -np.inf
+    if np.any(np.abs(r) > np.sqrt(np.finfo(np.float64).max) / 10.0):
+        return -np.inf
+    return -0.5 * (np.dot(r, r) + 2.0 * np.sum(np.log(e)))
+
+
+def lnprob(p, Jup, flux, eflux, bounds=None, T_d=None):
+    """emcee_radex.py:177-181 / emcee_radex_2comp.py:237-244: one walker through the engine."""
+    eng = globals()["R"]
+    if eng is None:
+        raise RuntimeError("call init_radex(tbg) first")
+    p = np.asarray(p, dtype=np.float64)
+    ncomp = p.size // 4
+    eng.set_source(eng._tbg, np.asarray(np.int_(Jup)), flux, eflux, bounds, ncomp, T_d, src=0)
+    return float(eng.lnprob_batch(p[None, :])[0])

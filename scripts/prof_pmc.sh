@@ -1,0 +1,26 @@
+#!/bin/bash
+# usage: scripts/prof_pmc.sh <outdir>   (run on the GPU box via gpurun)
+# Separate rocprofv3 passes: kernel-trace/stats, then PMC sets (never combined with trace domains).
+set -u
+OUT=${1:-gpurun_out/prof}
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc4 -- $CMD > $OUT/pmc4.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+for d in ("pmc1","pmc2","pmc3","pmc4"):
+    for f in glob.glob("$OUT/%s/*/*counter_collection.csv" % d):
+        acc = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if "rx_solve_kernel" in row["Kernel_Name"]:
+                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, v in sorted(acc.items()):
+            print("%-24s mean/dispatch %.6g  (n=%d)" % (k, sum(v)/len(v), len(v)))
+for f in glob.glob("$OUT/trace/*/*kernel_stats.csv"):
+    print(open(f).read())
+PY

@@ -1,0 +1,94 @@
+"""GPU tests of the host-side mirror of the reference interface: the `Radex` look-alike, the
+per-walker lnprob/model_lvg functions and the sampler driving the engine (config 1)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O                                  # noqa: E402 (checker only)
+from radex_emcee_amd import likelihood, workloads               # noqa: E402
+from radex_emcee_amd.radex import Radex                         # noqa: E402
+from radex_emcee_amd.sampler import EnsembleSampler             # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def mol(co_path):
+    return O.Molecule(co_path)
+
+
+def test_radex_lookalike_matches_oracle(mol):
+    """The call pattern of emcee/pyradex/tests/test_radex.py:175-200 (test_mod_params)."""
+    fo = 0.75
+    RR = Radex(species='co', density={'oH2': fo * 1e3, 'pH2': (1 - fo) * 1e3}, column=1e15,
+               temperature=20, tbackground=2.73)
+    niter = RR.run_radex()
+    ref = O.solve_state(mol, 2.73, {2: 250.0, 3: 750.0}, 20.0, 1e15)
+    assert niter == ref["niter"]
+    assert np.allclose(RR.tex[:6], ref["tex"][:6], rtol=1e-7)
+    assert np.allclose(RR.tau[:6], ref["tau"][:6], rtol=1e-7)
+    assert RR.level_population.shape == (41,) and abs(RR.level_population.sum() - 1) < 1e-9
+    RR.column = 1e14
+    RR.set_params(density={'oH2': fo * 1e4, 'pH2': (1 - fo) * 1e4}, temperature=25)
+    RR.run_radex(validate_colliders=False, reuse_last=True, reload_molfile=False)
+    ref = O.solve_state(mol, 2.73, {2: 2500.0, 3: 7500.0}, 25.0, 1e14)
+    assert np.allclose(RR.Tex[:6], ref["tex"][:6], rtol=1e-7)
+    st = O.State(mol); st.backrad(2.73); st.set_density({2: 2500.0, 3: 7500.0})
+    st.s.tkin, st.s.cdmol = 25.0, 1e14; st.rates(); st.run()
+    sb = np.asarray(getattr(RR.source_line_surfbrightness, "value", RR.source_line_surfbrightness))
+    assert np.allclose(sb[:8], st.surfbrightness()[:8], rtol=1e-7)
+    assert np.allclose(RR.upperlevelpop[:3], ref["xpop"][1:4], rtol=1e-7)
+    # the setters raise where pyradex does (core.py:734-735, 771-772)
+    with pytest.raises(ValueError):
+        RR.temperature = 1e5
+    with pytest.raises(ValueError):
+        RR.column = 1e26
+    with pytest.raises(ValueError):
+        RR.set_params(density={'He': 1e3})
+    with pytest.raises(ValueError):
+        Radex(species='co', density=1e3, column=1e14, temperature=20, escapeProbGeom='cube')
+    # total H2 density -> thermal ortho/para split (core.py:537-546, test_radex.py:140-160)
+    R2 = Radex(species='co', collider_densities={'H2': 1e4}, column_per_bin=1e14, temperature=30, tbackground=2.73)
+    opr = 9.0 * np.exp(-170.6 / 30)
+    assert abs(R2.density['oH2'] - opr / (1 + opr) * 1e4) < 1e-8
+    R2.temperature = 50
+    opr = 9.0 * np.exp(-170.6 / 50)
+    assert abs(R2.density['oH2'] - opr / (1 + opr) * 1e4) < 1e-8
+
+
+def test_per_walker_functions(mol):
+    cfg = workloads.config1(8)
+    likelihood.R = None
+    likelihood.init_radex(cfg["tbg"])
+    src0 = O.Source(cfg["tbg"], cfg["Jup"], np.ones(7), np.ones(7), cfg["bounds"])
+    truth = O.model_flux_batch(mol, src0, cfg["truth"][None, :])[0][0]
+    m = likelihood.model_lvg(cfg["Jup"], cfg["truth"])
+    assert np.allclose(m, truth, rtol=1e-7)
+    src = O.Source(cfg["tbg"], cfg["Jup"], truth, 0.1 * truth, cfg["bounds"])
+    for p in cfg["walkers"][:4]:
+        want = O.lnprob_batch(mol, src, p[None, :])[0][0]
+        got = likelihood.lnprob(p, cfg["Jup"], truth, 0.1 * truth, bounds=cfg["bounds"])
+        assert got == pytest.approx(want, rel=1e-7)
+        assert likelihood.lnlike(p, cfg["Jup"], truth, 0.1 * truth) == pytest.approx(want, rel=1e-7)
+        assert likelihood.lnprior(p, cfg["bounds"]) == 0.0
+    out = cfg["truth"].copy(); out[0] = 9.0
+    assert likelihood.lnprob(out, cfg["Jup"], truth, 0.1 * truth, bounds=cfg["bounds"]) == -np.inf
+    with pytest.raises(ValueError):
+        likelihood.model_lvg(cfg["Jup"], [4.0, 4.5, 15.0, -10.0])      # T = 10^4.5 K
+    assert likelihood.lnlike([4.0, 4.5, 15.0, -10.0], cfg["Jup"], truth, 0.1 * truth) == -np.inf
+
+
+def test_sampler_on_gpu_matches_sampler_on_oracle(mol):
+    """BASELINE config 1 in miniature: 400 walkers around the truth, stretch move, GPU lnprob per
+    half-step vs the same sampler fed by the CPU oracle."""
+    cfg = workloads.config1(400)
+    post = likelihood.Posterior(cfg["Jup"], np.ones(7), np.ones(7), cfg["bounds"], cfg["tbg"])
+    truth = post.model_lvg(cfg["truth"])[0]
+    post = likelihood.Posterior(cfg["Jup"], truth, 0.1 * truth, cfg["bounds"], cfg["tbg"], engine=post.engine)
+    src = O.Source(cfg["tbg"], cfg["Jup"], truth, 0.1 * truth, cfg["bounds"])
+    a = EnsembleSampler(400, 4, post.lnprob_batch, vectorize=True, seed=42)
+    b = EnsembleSampler(400, 4, lambda P: O.lnprob_batch(mol, src, P, nthreads=8)[0], vectorize=True, seed=42)
+    sa = a.run_mcmc(cfg["walkers"], 6)
+    sb = b.run_mcmc(cfg["walkers"], 6)
+    assert np.allclose(sa.log_prob, sb.log_prob, rtol=1e-6, atol=1e-6)
+    assert np.allclose(sa.coords, sb.coords, rtol=0, atol=1e-12)
+    assert a.get_chain().shape == (6, 400, 4) and a.acceptance_fraction.mean() > 0.1

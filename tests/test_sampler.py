@@ -1,0 +1,123 @@
+"""CPU tests of the ensemble sampler (stretch move) and of the multi-rank log-prob sharding
+(world_size-2 gloo).  The likelihood here is an analytic stand-in: the HIP engine needs a GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from radex_emcee_amd.sampler import EnsembleSampler, ShardedLogProb, State
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gauss_batch(P, mu, isig):
+    d = (P - mu) * isig
+    return -0.5 * np.sum(d * d, axis=1)
+
+
+def gauss_one(p, mu, isig):
+    d = (p - mu) * isig
+    return -0.5 * float(np.dot(d, d))
+
+
+def test_api_shapes_and_reset():
+    mu, isig = np.array([1.0, -2.0, 0.5, 3.0]), 1.0 / np.array([0.5, 1.0, 2.0, 0.1])
+    s = EnsembleSampler(32, 4, gauss_batch, args=(mu, isig), vectorize=True, seed=1)
+    p0 = mu + 1e-3 * np.random.RandomState(0).randn(32, 4)
+    st = s.run_mcmc(p0, 20, progress=False)
+    assert isinstance(st, State) and st.coords.shape == (32, 4) and st.log_prob.shape == (32,)
+    assert s.get_chain().shape == (20, 32, 4) and s.get_log_prob().shape == (20, 32)
+    assert s.get_chain(flat=True).shape == (640, 4) and s.get_log_prob(flat=True).shape == (640,)
+    assert s.nevals == 32 + 20 * 32
+    s.reset()
+    assert s.get_chain().shape == (0, 32, 4) and s.iteration == 0
+    st2 = s.run_mcmc(st, 5)
+    assert s.get_chain().shape == (5, 32, 4) and np.all(np.isfinite(st2.log_prob))
+    with pytest.raises(ValueError):
+        EnsembleSampler(6, 4, gauss_batch)
+
+
+def test_vectorized_and_per_walker_paths_agree():
+    mu, isig = np.zeros(3), np.ones(3)
+    p0 = np.random.RandomState(3).randn(16, 3)
+    a = EnsembleSampler(16, 3, gauss_batch, args=(mu, isig), vectorize=True, seed=7)
+    b = EnsembleSampler(16, 3, gauss_one, args=(mu, isig), seed=7)
+    sa, sb = a.run_mcmc(p0, 30), b.run_mcmc(p0, 30)
+    assert np.allclose(sa.coords, sb.coords, rtol=0, atol=1e-12)
+    assert np.array_equal(a.acceptance_fraction, b.acceptance_fraction)
+
+
+def test_stretch_move_samples_the_target():
+    rng = np.random.RandomState(11)
+    mu, sig = np.array([0.3, -1.0, 2.0, 0.0]), np.array([0.2, 1.5, 0.7, 1.0])
+    s = EnsembleSampler(64, 4, gauss_batch, args=(mu, 1.0 / sig), vectorize=True, seed=5)
+    st = s.run_mcmc(mu + 1e-3 * rng.randn(64, 4), 400)
+    s.reset()
+    s.run_mcmc(st, 1500)
+    flat = s.get_chain(flat=True)
+    assert np.all(np.abs(flat.mean(0) - mu) < 0.08 * sig + 0.02)
+    assert np.all(np.abs(flat.std(0) / sig - 1.0) < 0.08)
+    assert 0.3 < s.acceptance_fraction.mean() < 0.8
+
+
+def test_nan_and_minus_inf_handling():
+    def bad(P):
+        out = np.zeros(len(P)); out[0] = np.nan
+        return out
+    s = EnsembleSampler(8, 2, bad, vectorize=True, seed=0)
+    with pytest.raises(ValueError):
+        s.run_mcmc(np.random.RandomState(0).randn(8, 2), 1)
+
+    def box(P):          # -inf outside the unit box: proposals there are always rejected
+        return np.where(np.all(np.abs(P) < 1.0, axis=1), 0.0, -np.inf)
+    s = EnsembleSampler(16, 2, box, vectorize=True, seed=2)
+    st = s.run_mcmc(0.5 * (np.random.RandomState(1).rand(16, 2) - 0.5), 200)
+    assert np.all(np.abs(st.coords) < 1.0)
+
+
+WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from radex_emcee_amd.sampler import EnsembleSampler, ShardedLogProb
+rank, world, port = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=world)
+mu, isig = np.array([1.0, -2.0, 0.5, 3.0]), 1.0 / np.array([0.5, 1.0, 2.0, 0.1])
+calls = []
+def local(P):
+    calls.append(len(P))
+    d = (P - mu) * isig
+    return -0.5 * np.sum(d * d, axis=1)
+f = ShardedLogProb(local)
+s = EnsembleSampler(26, 4, f, vectorize=True, seed=123)        # 13 per half: ragged over 2 ranks
+p0 = mu + 1e-3 * np.random.RandomState(0).randn(26, 4)
+st = s.run_mcmc(p0, 25)
+np.save(sys.argv[5] + "/coords_%d.npy" % rank, st.coords)
+np.save(sys.argv[5] + "/calls_%d.npy" % rank, np.array(calls))
+# empty shard: fewer rows than ranks
+out = f(p0[:1])
+assert out.shape == (1,) and np.isfinite(out[0])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sharded_logprob_two_ranks_gloo(tmp_path):
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", str(port), str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    c0, c1 = np.load(tmp_path / "coords_0.npy"), np.load(tmp_path / "coords_1.npy")
+    assert np.array_equal(c0, c1)                          # every rank holds the same ensemble
+    # single-process reference run: identical chain
+    mu, isig = np.array([1.0, -2.0, 0.5, 3.0]), 1.0 / np.array([0.5, 1.0, 2.0, 0.1])
+    s = EnsembleSampler(26, 4, gauss_batch, args=(mu, isig), vectorize=True, seed=123)
+    st = s.run_mcmc(mu + 1e-3 * np.random.RandomState(0).randn(26, 4), 25)
+    assert np.array_equal(st.coords, c0)
+    k0, k1 = np.load(tmp_path / "calls_0.npy"), np.load(tmp_path / "calls_1.npy")
+    assert k0[0] == 13 and k1[0] == 13                     # initial 26 walkers split 13/13
+    assert set(k0[1:51]) == {7} and set(k1[1:51]) == {6}   # 13 proposals per half-step -> 7 + 6
