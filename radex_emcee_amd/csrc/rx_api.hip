@@ -223,10 +223,13 @@ lukernel_fn lukernel_for(int NL)
     return nullptr;
 }
 
-kernel_fn kernel_for(int NL, int occ)
+// exact = the molecule fills the instantiation (nlev == NL): only built for CO's 41 levels
+kernel_fn kernel_for(int NL, int occ, bool exact)
 {
+    if (NL == 41 && exact)
+        return occ >= 2 ? rxk::rx_solve_kernel<41, 2, true> : rxk::rx_solve_kernel<41, 1, true>;
     switch (NL) {
-#define RX_CASE(n) case n: return occ >= 2 ? rxk::rx_solve_kernel<n, 2> : rxk::rx_solve_kernel<n, 1>;
+#define RX_CASE(n) case n: return occ >= 2 ? rxk::rx_solve_kernel<n, 2, false> : rxk::rx_solve_kernel<n, 1, false>;
         RX_NL_CASES
 #undef RX_CASE
     }
@@ -380,7 +383,7 @@ int launch(rx_handle *h, const RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullp
     const long cap = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    kernel_fn k = kernel_for(h->NL, occ);
+    kernel_fn k = kernel_for(h->NL, occ, h->mol.nlev == h->NL);
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
     if (e0) HIPCHK(h, hipEventRecord(e0, st));
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, a);
@@ -456,7 +459,7 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
     int nb = 0;
-    kernel_fn k = kernel_for(h->NL, 2);
+    kernel_fn k = kernel_for(h->NL, 2, h->mol.nlev == h->NL);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
         h->blocks_per_cu2 = std::min(nb, 2);
     char nm[64];
