@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--walkers", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-batch", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -171,6 +172,15 @@ def main():
                      "frac": fl / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "flops_per_eval": round(flops_per_eval(niter_mean), 1)},
         }
+        if world == 1 and args.walkers == 1024 and not args.no_large_batch:
+            # throughput regime for reference (not the headline): 32768 walkers, 2 waves per SIMD
+            cfgL = workloads.config2(32768, seed=5678)
+            PL = torch.from_numpy(cfgL["walkers"]).to(dev)
+            oL = [torch.empty(32768, dtype=t, device=dev) for t in (torch.float64, torch.int32, torch.int32)]
+            eng.lnprob_batch_torch(PL, *oL, stream=stream)
+            msL = eng.time_lnprob_torch(PL, *oL, reps=5, stream=stream)
+            out["large_batch"] = {"walkers": 32768, "kernel_ms": round(msL, 3),
+                                  "value": round(32768 / (msL * 1e-3), 1), "unit": "evals/s"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, truth_flux)
         print(json.dumps(out))

@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/prof}
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-large-batch"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
