@@ -73,6 +73,20 @@ def cpu_baseline(cfg, truth_flux, seconds=15.0):
                       "team sizes 1..%d); %d walkers on 1 thread" % (reps, cores, dta, avail, n1)}
 
 
+def _measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/latest_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate passes by
+    scripts/prof_pmc.sh on this same command).  rocprofv3 reports KiB; FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-B requests at 64 B)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc_summary.json")))["counters"]
+        return {"bytes_per_launch": int((2.0 * d["FETCH_SIZE"]["mean_per_dispatch"]
+                                         + d["WRITE_SIZE"]["mean_per_dispatch"]) * 1024),
+                "source": "profiles/latest_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    except Exception:
+        return None
+
+
 def _cgroup_cpu_max():
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -172,6 +186,7 @@ def main():
                      "frac": fl / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "flops_per_eval": round(flops_per_eval(niter_mean), 1)},
         }
+        out["roofline"]["traffic"] = _measured_traffic()
         if world == 1 and args.walkers == 1024 and not args.no_large_batch:
             # throughput regime for reference (not the headline): 32768 walkers, 2 waves per SIMD
             cfgL = workloads.config2(32768, seed=5678)

@@ -1,0 +1,116 @@
+"""Per-source fitting driver: the callers around the hot path.
+
+Mirrors the parts of `main()` in /root/reference/emcee/emcee_radex.py:382-531 and
+emcee/emcee_radex_2comp.py:480-611 that surround the likelihood:
+  per-source set-up (tbg, bounds, p0) -> optional warm start (curve_fit, minimize; f-4)
+  -> burn-in + production chains with the GPU-batched sampler (f-1)
+  -> result tuple/pickle with the reference's layout (f-3) -> 16/50/84 percentile summary.
+Plotting (`replot`, corner) is out of scope.
+"""
+from __future__ import annotations
+
+import pickle
+
+import numpy as np
+
+from . import data_io, workloads
+from .likelihood import Posterior
+from .sampler import EnsembleSampler
+
+P0_1COMP = [4.0, 1.4, 17.8, -9.85]                                   # emcee_radex.py:444-447
+P0_2COMP = [1.9, 1.2, 16.4, -12.1, 3.9, 2.5, 17.5, -12.1]            # emcee_radex_2comp.py:513-522
+
+
+def warm_start(post: Posterior, p0, use_curve_fit=True, use_minimize=True):
+    """curve_fit (bounded TRF) then minimize(-lnprob) (L-BFGS-B) as in emcee_radex.py:453-468.
+    Returns (popt, pcov, pmin).  Serial N=1 calls through the same engine."""
+    from scipy.optimize import curve_fit, minimize
+    bounds = post.bounds
+    p0 = np.clip(np.asarray(p0, dtype=float), bounds[:, 0], bounds[:, 1])
+    popt, pcov = p0, None
+    if use_curve_fit:
+        def opt_fun(_J, *p):
+            m = post.model_lvg(np.asarray(p)[None, :])[0]
+            return np.where(np.isfinite(m), m, 1e300)
+        try:
+            popt, pcov = curve_fit(opt_fun, post.Jup, post.flux, sigma=post.eflux, p0=p0,
+                                   bounds=list(zip(*bounds)))
+        except (RuntimeError, ValueError):
+            popt, pcov = p0, None                                   # "curve_fit : failed" -> p0
+    pmin = popt
+    if use_minimize:
+        def nll(p):
+            v = -post.lnprob(p)
+            return v if np.isfinite(v) else 1e300
+        res = minimize(nll, popt, bounds=bounds)
+        pmin = res.x
+    return np.asarray(popt), pcov, np.asarray(pmin)
+
+
+def summarize(flatchain, ncomp=1):
+    """16/50/84 percentiles of (log n, log T, log N, log P = log n + log T) per component as
+    (median, +err, -err) triples (emcee_radex.py:511-531)."""
+    out = []
+    for c in range(ncomp):
+        ch = flatchain[:, 4 * c:4 * c + 4]
+        plot = np.hstack((ch[:, [0, 1, 2]], ch[:, [0]] + ch[:, [1]]))
+        pc = np.percentile(plot, [16, 50, 84], axis=0)
+        out.append({name: (pc[1, i], pc[2, i] - pc[1, i], pc[1, i] - pc[0, i])
+                    for i, name in enumerate(("n_H2", "T_kin", "N_CO", "P"))})
+    return out
+
+
+def result_tuple(source, z, bounds, Jup, flux, eflux, popt, pcov, pmin, theta_med, chain, lnprobability,
+                 T_d=None):
+    """(source, z, bounds[, T_d], (Jup, flux, eflux), (popt, pcov), pmin, theta_med, (chain, lnprob))
+    -- emcee_radex.py:504-509; the 2-component script inserts T_d after bounds (:580-585)."""
+    head = (source, z, bounds) + ((T_d,) if T_d is not None else ())
+    return head + ((Jup, flux, eflux), (popt, pcov), pmin, theta_med, (chain, lnprobability))
+
+
+def save_result(path, tup):
+    with open(path, "wb") as f:
+        pickle.dump(tup, f)
+
+
+def load_result(path):
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
+def fit_source(source, data, ncomp=1, nwalkers=None, n_iter_burn=100, n_iter_walk=None, seed=None,
+               engine=None, warm=True, lnprob_wrapper=None):
+    """One source end to end.  Defaults are the reference's: 100 walkers x (100 + 500) steps for
+    one component, 400 x (100 + 1000) for two (emcee_radex.py:472-474, 2comp:548-550)."""
+    if ncomp == 1:
+        z, _lw, Jup, flux, eflux = data_io.get_source(source, data)
+        T_d, p0 = None, P0_1COMP
+        nwalkers = nwalkers or 100
+        n_iter_walk = n_iter_walk or 500
+    else:
+        z, T_d, _lw, Jup, flux, eflux = data_io.get_source(source, data)
+        p0 = P0_2COMP
+        nwalkers = nwalkers or 400
+        n_iter_walk = n_iter_walk or 1000
+    tbg, bounds = data_io.source_setup(z, ncomp)
+    post = Posterior(Jup, flux, eflux, bounds, tbg, ncomp=ncomp, T_d=T_d, engine=engine)
+    if warm:
+        popt, pcov, pmin = warm_start(post, p0)
+    else:
+        popt = np.clip(np.asarray(p0, dtype=float), bounds[:, 0], bounds[:, 1])
+        pcov, pmin = None, popt
+    ndim = len(popt)
+    rng = np.random.RandomState(seed)
+    pos = popt + 1e-3 * rng.randn(nwalkers, ndim)                    # emcee_radex.py:477
+    fn = post.lnprob_batch if lnprob_wrapper is None else lnprob_wrapper(post.lnprob_batch)
+    sampler = EnsembleSampler(nwalkers, ndim, fn, vectorize=True, seed=seed)
+    state = sampler.run_mcmc(pos, n_iter_burn, progress=False)
+    sampler.reset()
+    sampler.run_mcmc(state, n_iter_walk, progress=False)
+    chain = sampler.get_chain()
+    lnprobability = sampler.get_log_prob()
+    flat = sampler.get_chain(flat=True)
+    theta_med = np.percentile(flat, 50, axis=0)
+    tup = result_tuple(source, z, bounds, Jup, flux, eflux, popt, pcov, pmin, theta_med, chain,
+                       lnprobability, T_d=T_d)
+    return tup, summarize(flat, ncomp), sampler

@@ -140,8 +140,9 @@ class EnsembleSampler:
             rint = rng.randint(Nc, size=(Ns,))
             q = c[rint] - (c[rint] - s) * zz[:, None]
             new_lp = self.compute_log_prob(q)
-            lnpdiff = factors + new_lp - state.log_prob[all_inds[S1]]
-            accepted = np.log(rng.rand(Ns)) < lnpdiff
+            with np.errstate(invalid="ignore"):          # (-inf) - (-inf) = NaN -> rejected, as in emcee
+                lnpdiff = factors + new_lp - state.log_prob[all_inds[S1]]
+                accepted = np.log(rng.rand(Ns)) < lnpdiff
             idx = all_inds[S1][accepted]
             state.coords[idx] = q[accepted]
             state.log_prob[idx] = new_lp[accepted]

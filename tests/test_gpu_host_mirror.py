@@ -92,3 +92,26 @@ def test_sampler_on_gpu_matches_sampler_on_oracle(mol):
     assert np.allclose(sa.log_prob, sb.log_prob, rtol=1e-6, atol=1e-6)
     assert np.allclose(sa.coords, sb.coords, rtol=0, atol=1e-12)
     assert a.get_chain().shape == (6, 400, 4) and a.acceptance_fraction.mean() > 0.1
+
+
+def test_fit_source_end_to_end(tmp_path):
+    """table reader -> set-up -> warm start -> sampler -> result tuple -> summary."""
+    from radex_emcee_amd import data_io, fit
+    data = data_io.read_data()
+    tup, summ, sampler = fit.fit_source("SDP81", data, nwalkers=32, n_iter_burn=5, n_iter_walk=10, seed=3)
+    assert tup[0] == "SDP81" and len(tup) == 8
+    chain, lnp = tup[7]
+    assert chain.shape == (10, 32, 4) and lnp.shape == (10, 32) and np.all(np.isfinite(lnp))
+    b = tup[2]
+    assert np.all(chain >= b[:, 0]) and np.all(chain <= b[:, 1])
+    assert set(summ[0]) == {"n_H2", "T_kin", "N_CO", "P"}
+    popt, pmin = tup[4][0], tup[5]
+    post = fit.Posterior(*tup[3], b, data_io.source_setup(tup[1])[0])
+    assert post.lnprob(pmin) >= post.lnprob(np.clip(fit.P0_1COMP, b[:, 0], b[:, 1])) - 1e-9   # minimize improved on p0
+    fit.save_result(tmp_path / "SDP81_bounds.pickle", tup)
+    assert fit.load_result(tmp_path / "SDP81_bounds.pickle")[0] == "SDP81"
+    # 2-component table (T_d column), no warm start
+    data2 = data_io.read_data(data_io.FLUX_2COMP)
+    tup2, summ2, _ = fit.fit_source("SDP81", data2, ncomp=2, nwalkers=32, n_iter_burn=2, n_iter_walk=3, seed=1,
+                                    warm=False)
+    assert len(tup2) == 9 and tup2[3] == 34.0 and tup2[8][0].shape == (3, 32, 8) and len(summ2) == 2
