@@ -198,7 +198,9 @@ struct rx_handle {
     int num_cu = 256, blocks_per_cu2 = 1;
     // staging for the host-pointer API + 2-component scratch
     DevBuf<double> s_params, s_lnp, s_flux, s_cflux, s_in3, s_dens, s_xpop, s_tex, s_tau, s_sb;
-    DevBuf<int32_t> s_src, s_status, s_niter, s_cstatus, s_cniter;
+    DevBuf<int32_t> s_src, s_status, s_niter, s_cstatus, s_cniter, s_srcfix;
+    int srcfix_value = -1;
+    size_t srcfix_filled = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -373,9 +375,26 @@ int fill_args(rx_handle *h, RxKArgs &a, int N, int ncomp, int mode)
     return 0;
 }
 
-int launch(rx_handle *h, const RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
+// The kernels always read src_index[w]; callers that address one source get a handle-owned
+// array filled with that slot (refilled only when the slot or the batch size changes).
+int fixed_src_index(rx_handle *h, RxKArgs &a, hipStream_t st)
+{
+    if (a.src_index || a.N <= 0) return 0;
+    const size_t n = (size_t)a.N;
+    if (h->s_srcfix.n < n) { HIPCHK(h, h->s_srcfix.reserve(std::max(n, (size_t)4096))); h->srcfix_filled = 0; }
+    if (h->srcfix_value != a.src_fixed || h->srcfix_filled < n) {
+        HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->s_srcfix.p, a.src_fixed, h->s_srcfix.n, st));
+        h->srcfix_value = a.src_fixed;
+        h->srcfix_filled = h->s_srcfix.n;
+    }
+    a.src_index = h->s_srcfix.p;
+    return 0;
+}
+
+int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     if (a.N <= 0) return 0;
+    { int rc = fixed_src_index(h, a, st); if (rc) return rc; }
     const int ncomp = (a.mode == RXK_MODE_SOLVE) ? 1 : a.ncomp;
     const long items = (long)a.N * ncomp;
     long blocks = (items + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK;
@@ -481,7 +500,7 @@ void rx_destroy(rx_handle *h)
     h->s_params.release(); h->s_lnp.release(); h->s_flux.release(); h->s_cflux.release();
     h->s_in3.release(); h->s_dens.release(); h->s_xpop.release(); h->s_tex.release();
     h->s_tau.release(); h->s_sb.release(); h->s_src.release(); h->s_status.release();
-    h->s_niter.release(); h->s_cstatus.release(); h->s_cniter.release();
+    h->s_niter.release(); h->s_cstatus.release(); h->s_cniter.release(); h->s_srcfix.release();
     delete h;
 }
 

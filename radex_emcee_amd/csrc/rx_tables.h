@@ -70,7 +70,8 @@ struct RxKArgs {
     RxMolDev mol;
     const RxSourceDev *srcs;
     const double *params;           // [N][4*ncomp] log10
-    const int32_t *src_index;       // [N] or null
+    const int32_t *src_index;       // [N] source slot per walker; never null on the device (the host
+                                    //   substitutes a handle-owned array filled with the fixed slot)
     int32_t src_fixed;
     int32_t N, ncomp, mode, method, miniter, maxiter;
     int32_t h2_total;               // data file lists 'H2' (id 1): density[0] = pH2+oH2 (core.py:551-554)

@@ -299,3 +299,63 @@ def test_device_pointer_api_on_side_stream(engines, mol):
     assert np.array_equal(lnp.cpu().numpy(), host)
     ms = eng.time_lnprob_torch(P, lnp, st, nit, reps=2)
     assert 0.0 < ms < 1000.0
+
+
+@pytest.mark.parametrize("nlev", [5, 12, 20, 27, 33, 45, 64])
+def test_every_kernel_instantiation(nlev, tmp_path):
+    """Synthetic rotor ladders of different sizes exercise each padded instantiation
+    (NL = 8, 20, 32, 41, 48, 64), with and without padding levels, against the oracle."""
+    from radex_emcee_amd.molecule import synth_co_text
+    path = tmp_path / ("rotor%d.dat" % nlev)
+    path.write_text(synth_co_text(nlev=nlev))
+    eng = Engine(str(path))
+    mol = O.Molecule(str(path))
+    assert eng.nlev == nlev and eng.nline == nlev - 1
+    z = 2.5
+    b = workloads.bounds_1comp(z)
+    tbg = workloads.T_CMB0 * (1 + z)
+    P = workloads.draw_prior_1comp(b, 48, 900 + nlev)
+    Jup = [j for j in (1, 2, 3, 4) if j < nlev]
+    eng.set_source(tbg, Jup, np.ones(len(Jup)), 0.2 * np.ones(len(Jup)), b)
+    src = O.Source(tbg, Jup, np.ones(len(Jup)), 0.2 * np.ones(len(Jup)), b)
+    flux, st, nit = eng.model_flux_batch(P, return_info=True)
+    rf, rst, rnit = O.model_flux_batch(mol, src, P)
+    assert np.array_equal(st, rst), nlev
+    assert (nit == rnit).mean() >= 0.95
+    same = nit == rnit
+    ok, d = _flux_ok(flux[same], rf[same], P[same], tbg, mol)
+    assert ok.all(), (nlev, d[~ok][:4])
+    lnp = eng.lnprob_batch(P)
+    rl = O.lnprob_batch(mol, src, P)[0]
+    fin = np.isfinite(rl) & same
+    assert np.array_equal(np.isfinite(rl), np.isfinite(lnp))
+    assert np.max(np.abs(lnp[fin] - rl[fin]) / np.maximum(np.abs(rl[fin]), 1.0)) < 1e-6
+
+
+def test_batch_shapes_and_limits(engines, mol):
+    eng = engines[2]
+    cfg = workloads.config2(1030)
+    src = _truth_source(eng, mol, cfg)
+    full = eng.lnprob_batch(cfg["walkers"])
+    assert eng.lnprob_batch(np.empty((0, 4))).shape == (0,)                # empty batch
+    for n in (1, 3, 5, 255, 257, 1030):                                     # ragged sizes, tail of the work queue
+        assert np.array_equal(eng.lnprob_batch(cfg["walkers"][:n]), full[:n]), n
+    # nJ = 0: likelihood is the prior only (chi2 = 0, log term = 0)
+    eng.set_source(cfg["tbg"], [], [], [], cfg["bounds"])
+    lp = eng.lnprob_batch(cfg["walkers"][:8])
+    assert np.all(lp == 0.0)
+    # all source slots can be resident at once; out-of-range slots are rejected by the host API
+    for k in range(64):
+        eng.set_source(cfg["tbg"] * (1 + 0.001 * k), cfg["Jup"], src.flux, src.eflux, cfg["bounds"], src=k)
+    idx = (np.arange(128) % 64).astype(np.int32)
+    a = eng.lnprob_batch(cfg["walkers"][:128], src_index=idx)
+    assert np.isfinite(a).sum() > 100 and not np.array_equal(a[:64], a[64:128])
+    from radex_emcee_amd.engine import EngineError
+    with pytest.raises(EngineError):
+        eng.set_source(cfg["tbg"], cfg["Jup"], src.flux, src.eflux, cfg["bounds"], src=64)
+    with pytest.raises(EngineError):
+        eng.set_source(cfg["tbg"], [99], [1.0], [1.0], cfg["bounds"])       # Jup beyond the line list
+    with pytest.raises(EngineError):
+        eng.set_source(-1.0, cfg["Jup"], src.flux, src.eflux, cfg["bounds"])
+    with pytest.raises(EngineError):
+        eng.lnprob_batch(cfg["walkers"][:4], src_index=np.array([0, 1, 2, 77], dtype=np.int32))
