@@ -1,6 +1,5 @@
-"""Per-iteration latency of ablated kernel builds (diagnostic; results of ablated builds are wrong
-by construction).  Usage: python scripts/ablate.py scripts/abl/*.so"""
-import os, subprocess, sys, json
+"""Kernel time of alternative builds on the bench workload.  Usage: python scripts/ablate.py scripts/abl/*.so"""
+import os, subprocess, sys
 CHILD = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
@@ -11,15 +10,12 @@ e = Engine()
 e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
 P = torch.from_numpy(cfg["walkers"]).cuda()
 lnp = torch.empty(1024, dtype=torch.float64, device="cuda"); st = torch.empty(1024, dtype=torch.int32, device="cuda"); nit = torch.empty_like(st)
-out = {}
-for mi in (20, 60):
-    e.set_iteration_limits(10, mi)
-    e.time_lnprob_torch(P, lnp, st, nit, reps=3)
-    out[mi] = e.time_lnprob_torch(P, lnp, st, nit, reps=20)
-print("RESULT", (out[60]-out[20])/40.0*1e3, out[20], out[60], int(nit.min()), int(nit.max()))
+e.time_lnprob_torch(P, lnp, st, nit, reps=3)
+ms = e.time_lnprob_torch(P, lnp, st, nit, reps=20)
+print("RESULT %.4f ms  sum(lnp finite)=%.6e niter_sum=%d" % (ms, float(lnp[torch.isfinite(lnp)].sum()), int(nit.sum())))
 '''
 for lib in sys.argv[1:]:
     env = dict(os.environ, RADEX_EMCEE_AMD_LIB=os.path.abspath(lib))
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-    print("%-40s %s" % (os.path.basename(lib), line[0] if line else r.stderr[-300:]))
+    print("%-28s %s" % (os.path.basename(lib), line[0] if line else r.stderr[-300:]))
