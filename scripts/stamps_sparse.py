@@ -1,0 +1,12 @@
+import os, sys
+os.environ["RADEX_EMCEE_AMD_LIB"] = os.path.abspath(sys.argv[1]); os.environ["RX_STAMP_FILE"] = "/tmp/stamps.bin"
+sys.path.insert(0, ".")
+import numpy as np
+from radex_emcee_amd.engine import Engine
+from radex_emcee_amd import workloads
+cfg = workloads.config2(1024); e = Engine(); e.set_source(cfg["tbg"]); W = cfg["walkers"]; n = 10 ** W[:, 0]
+r = e.solve_batch(10 ** W[:, 1], 10 ** W[:, 2], np.stack([0.25 * n, 0.75 * n], 1))
+d = np.fromfile("/tmp/stamps.bin").reshape(1024, 64)
+slots = [int(x) for x in sys.argv[2].split(",")]
+for a, b in zip(slots[:-1], slots[1:]):
+    print("slot %d -> %d: median %.0f ticks" % (a, b, np.median(d[:, b] - d[:, a])))
