@@ -12,15 +12,22 @@ rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACT
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc4 -- $CMD > $OUT/pmc4.log 2>&1
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
+summary = {"command": "rocprofv3 --pmc <set> -- $CMD (one pass per counter set, scripts/prof_pmc.sh)",
+           "workload": "1024 config-2 walkers per dispatch", "counters": {},
+           "notes": "FETCH_SIZE/WRITE_SIZE are in KiB as reported by rocprofv3; SQ_*_CYCLES/SQ_ACTIVE_*/SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md)"}
 for d in ("pmc1","pmc2","pmc3","pmc4"):
     for f in glob.glob("$OUT/%s/*/*counter_collection.csv" % d):
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             if "rx_solve_kernel" in row["Kernel_Name"]:
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                summary["kernel"] = row["Kernel_Name"]
         for k, v in sorted(acc.items()):
             print("%-24s mean/dispatch %.6g  (n=%d)" % (k, sum(v)/len(v), len(v)))
+            summary["counters"][k] = {"mean_per_dispatch": sum(v)/len(v), "dispatches": len(v)}
+json.dump(summary, open("$OUT/pmc_summary.json", "w"), indent=1)
 for f in glob.glob("$OUT/trace/*/*kernel_stats.csv"):
     print(open(f).read())
+    open("$OUT/kernel_stats.csv", "w").write(open(f).read())
 PY
