@@ -59,6 +59,50 @@ def test_lubksb_vs_reference_binary(engines, golden_dir):
         assert np.max(np.abs(x - want) / np.abs(want)) < 1e-10, n
 
 
+@pytest.mark.parametrize("n", [3, 8, 9, 20, 21, 32, 41, 45, 48, 64])
+def test_lubksb_random_vs_oracle(engines, n, tmp_path):
+    """The LU alone on matrices that are nothing like a rate matrix: an interchange at almost every
+    step (gaussian), exact ties between candidates (small integers; isamax's first-maximum rule),
+    singular systems (sgeir_ returns without solving: x stays e_last).  n <= 41 runs in the CO
+    engine's padded <41> kernel, the other sizes in the instantiation of a rotor with n levels."""
+    rng = np.random.RandomState(1000 + n)
+    eng = engines[2]
+    if n in (8, 20, 32, 45, 48, 64):
+        from radex_emcee_amd.molecule import synth_co_text
+        path = tmp_path / ("rotor%d.dat" % n)
+        path.write_text(synth_co_text(nlev=n))
+        eng = Engine(str(path))
+    mats = []
+    for _ in range(12):
+        mats.append(rng.randn(n, n))
+    for _ in range(12):
+        mats.append(rng.randint(-2, 3, size=(n, n)).astype(float))
+    for _ in range(4):                                   # rate-matrix like: dominant diagonal
+        a = -rng.rand(n, n) * 10.0 ** rng.uniform(-12, 0, size=(n, n))
+        a[np.arange(n), np.arange(n)] = -a.sum(axis=0) + a.diagonal()
+        mats.append(a)
+    nexact = len(mats)
+    for _ in range(4):                                   # exactly singular: a zero balance equation
+        a = rng.randn(n, n)                              #   (stays zero through the elimination)
+        a[rng.randint(0, n - 1)] = 0.0
+        mats.append(a)
+    A = np.array(mats)
+    x = eng.lubksb_batch(A)
+    for m, a in enumerate(mats):
+        want, info = O.lubksb(a)
+        if m >= nexact:
+            assert info != 0
+            assert np.array_equal(x[m], want), (n, m, "singular system must return e_last")
+            continue
+        aa = a.copy()
+        aa[n - 1] = 1.0
+        cond = np.linalg.cond(aa)
+        if info != 0 or cond > 1e10:      # numerically singular integer draws: rounding decides, no parity claim
+            continue
+        err = np.max(np.abs(x[m] - want)) / np.max(np.abs(want))
+        assert err <= 1e-13 * cond + 1e-12, (n, m, err, cond)
+
+
 def test_solve_vs_reference_binary(engines, golden_dir, toy_path):
     g = json.load(open(os.path.join(golden_dir, "ref_matrix.json")))
     toy = {m: Engine(toy_path, escapeProbGeom=n) for m, n in ((1, "sphere"), (2, "lvg"))}
