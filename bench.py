@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--walkers", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-batch", action="store_true")
+    ap.add_argument("--no-sampler", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -113,10 +114,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RX_BENCH_SHARE_GPU=1: every rank uses GPU 0 and the rendezvous runs over gloo -- only to
+    # exercise the multi-rank control flow on a one-GPU box; RCCL needs one GPU per rank.
+    share = os.environ.get("RX_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -148,7 +157,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -196,6 +205,21 @@ def main():
             msL = eng.time_lnprob_torch(PL, *oL, reps=5, stream=stream)
             out["large_batch"] = {"walkers": 32768, "kernel_ms": round(msL, 3),
                                   "value": round(32768 / (msL * 1e-3), 1), "unit": "evals/s"}
+        if world == 1 and not args.no_sampler:
+            # the caller of the path: stretch-move chain, walkers in a ball around the
+            # truth like emcee_radex.py:477, two half-ensemble launches per step, host buffers
+            from radex_emcee_amd.sampler import EnsembleSampler
+            rs = np.random.RandomState(99)
+            p0 = cfg["truth"] + 1e-3 * rs.randn(args.walkers, 4)
+            smp = EnsembleSampler(args.walkers, 4, eng.lnprob_batch, vectorize=True, seed=7)
+            state = smp.run_mcmc(p0, 5, progress=False)
+            ts = time.perf_counter()
+            smp.run_mcmc(state, 40, progress=False)
+            tsd = time.perf_counter() - ts
+            out["sampler"] = {"walker_steps_per_s": round(args.walkers * 40 / tsd, 1), "steps": 40,
+                              "ms_per_step": round(tsd / 40 * 1e3, 3),
+                              "acceptance": round(float(smp.acceptance_fraction.mean()), 3),
+                              "note": "EnsembleSampler on the host (numpy) + rx_lnprob_batch; PCIe inclusive"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, truth_flux)
         print(json.dumps(out))
