@@ -256,7 +256,7 @@ int build_tables(rx_handle *h)
     for (int i = 0; i < m.nlev; ++i) { LV.eterm[i] = m.eterm[i]; LV.gstat[i] = m.gstat[i]; }
     RxLineTab LT;
     memset(&LT, 0, sizeof LT);
-    for (int l = 0; l < RXK_MAXLINES; ++l) { LT.gm[l] = LT.gn[l] = 1.0; LT.aein[l] = 1.0; LT.fgxta[l] = 1.0; LT.thcxt[l] = 1.0; }
+    for (int l = 0; l < RXK_MAXLINES; ++l) { LT.gm[l] = LT.gn[l] = 1.0; LT.aein[l] = 1.0; LT.fgxta[l] = 1.0; LT.thcxt[l] = 1.0; LT.rgn[l] = LT.rfgxta[l] = LT.rthcxt[l] = 1.0; }
     for (int l = 0; l < m.nline; ++l) {
         const int mu = m.iupp[l] - 1, nl_ = m.ilow[l] - 1;
         const double A = m.aeinst[l], gm = m.gstat[mu], gn = m.gstat[nl_];
@@ -267,6 +267,7 @@ int build_tables(rx_handle *h)
         LT.agmgn[l] = A * (gm / gn);
         LT.fgxta[l] = H_FGAUS * xt / A;
         LT.thcxt[l] = xt * H_THC;
+        LT.rgn[l] = 1.0 / LT.gn[l]; LT.rfgxta[l] = 1.0 / LT.fgxta[l]; LT.rthcxt[l] = 1.0 / LT.thcxt[l];
         LT.fkxnu[l] = H_FK * xnu;
         LT.thcxt_py[l] = H_THC_PY * xt;
         LT.fkxnu_py[l] = H_FK_PY * xnu;

@@ -25,6 +25,9 @@ struct RxLineTab {
     double fkxnu[RXK_MAXLINES];     // fk*xnu          (Fortran constants)
     double thcxt_py[RXK_MAXLINES];  // thc_py*xt       (astropy constants, core.py:981-984)
     double fkxnu_py[RXK_MAXLINES];  // fk_py*xnu
+    // correctly rounded reciprocals of the three per-line divisors: x / c is evaluated as
+    // q = x*rc; q += fma(-q, c, x)*rc, which rounds like the division (rx_kernel: div_const)
+    double rgn[RXK_MAXLINES], rfgxta[RXK_MAXLINES], rthcxt[RXK_MAXLINES];
 };
 
 // Lines incident to each level, in line order (CSR).  entry = line | other<<8 | role<<16,
