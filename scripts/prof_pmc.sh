@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/prof}
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-large-batch"
+CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-large-batch --no-sampler"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
@@ -27,7 +27,19 @@ for d in ("pmc1","pmc2","pmc3","pmc4"):
             print("%-24s mean/dispatch %.6g  (n=%d)" % (k, sum(v)/len(v), len(v)))
             summary["counters"][k] = {"mean_per_dispatch": sum(v)/len(v), "dispatches": len(v)}
 json.dump(summary, open("$OUT/pmc_summary.json", "w"), indent=1)
-for f in glob.glob("$OUT/trace/*/*kernel_stats.csv"):
+for f in sorted(glob.glob("$OUT/trace/*/*kernel_stats.csv"))[:1]:
     print(open(f).read())
     open("$OUT/kernel_stats.csv", "w").write(open(f).read())
+# the stats file averages over every dispatch of the kernel, including the one-walker set-up call
+# of bench.py; split by grid size so that the 1024-walker launches can be read off directly
+for f in sorted(glob.glob("$OUT/trace/*/*kernel_trace.csv"))[:1]:
+    by = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if "rx_solve_kernel" in row["Kernel_Name"]:
+            by[int(row["Grid_Size_X"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    with open("$OUT/kernel_by_grid.csv", "w") as o:
+        o.write("kernel,grid_size_x,workgroups,calls,average_ns,min_ns,max_ns\n")
+        for g, v in sorted(by.items()):
+            line = "rx_solve_kernel,%d,%d,%d,%.1f,%d,%d" % (g, g // 256, len(v), sum(v) / len(v), min(v), max(v))
+            print(line); o.write(line + "\n")
 PY
