@@ -160,3 +160,34 @@ def test_reference_kats_when_real_co_dat_is_supplied():
     r = O.solve_state(m, 2.73, {2: 1e4 * (1 - fo), 3: 1e4 * fo}, 30.0, 1e14)
     assert r["tex"][0] == pytest.approx(56.131, rel=1e-4)
     assert r["tau"][0] == pytest.approx(1.786e-3, rel=1e-3)
+
+
+def test_linpack_positions_can_be_replayed_from_the_pivot_history():
+    """The kernel moves pivot rows physically into lane k and does not track the position LINPACK's
+    sgefa_ would have each row at; pivot_exact (rx_kernel.hip.inc) replays the positions from the
+    pivot history when two candidates tie exactly.  Same replay in Python against a plain
+    simulation of sgefa_'s interchanges (oracle/radex_oracle.c lin_gefa)."""
+    rng = np.random.RandomState(5)
+    for n in (3, 7, 41, 64):
+        for _ in range(50):
+            # an arbitrary pivot history: the pivot ROW of each step (any permutation is reachable)
+            order = list(rng.permutation(n))
+            for kk in (0, 1, n // 2, n - 1):
+                # plain sgefa_: rows start at position = index; step j swaps positions j and l
+                at = list(range(n))                   # at[position] = row
+                for j in range(kk):
+                    l = at.index(order[j])
+                    at[j], at[l] = at[l], at[j]
+                want = {row: posn for posn, row in enumerate(at)}
+                # kernel-style replay: lane j < kk holds the pivot row of step j, the other rows
+                # sit in arbitrary lanes >= kk (here: in a random arrangement)
+                rest = [r for r in range(n) if r not in order[:kk]]
+                rng.shuffle(rest)
+                lrow = order[:kk] + rest              # lrow[lane] = row held by that lane
+                pos = list(lrow)
+                for j in range(kk):
+                    l = pos[j]
+                    pos = [l if p == j else p for p in pos]
+                    pos[j] = j
+                got = {lrow[lane]: pos[lane] for lane in range(n)}
+                assert got == want
