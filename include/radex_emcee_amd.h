@@ -142,8 +142,9 @@ int rx_solve_batch(rx_handle *h, int src, int N, const double *tkin,
 /* Replaces lubksb_(a, n, np, indx, b) as patched by pyradex (radex.so lubksb_ -> sgeir_,
  * SURVEY.md A.5; called from matrix_): for each of N systems A[n][n] (row-major, n <= the
  * handle's padded level count) the last row is replaced by ones, rhs = e_last, and the
- * solution of the LU with partial pivoting is returned in x[N][n].  Host pointers.  Exposed
- * so the pivoted solve can be checked on its own against the reference's lubksb_ vectors. */
+ * solution by elimination with LINPACK's partial pivoting (sgefa_'s pivot choices; x = e_last on
+ * a singular system, as sgeir_ leaves it) is returned in x[N][n].  Host pointers.  Exposed so
+ * the pivoted solve can be checked on its own against the reference's lubksb_ vectors. */
 int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x);
 
 /* Kernel timing hook for bench.py: runs rx_lnprob_batch_device `reps` times
