@@ -147,6 +147,12 @@ int rx_solve_batch(rx_handle *h, int src, int N, const double *tkin,
  * the pivoted solve can be checked on its own against the reference's lubksb_ vectors. */
 int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x);
 
+/* Same, and also the pivot choices: pivrow[N][n] (optional) receives, for every system, the index
+ * of the row chosen as pivot of step 0, 1, ..., n-1 -- sgefa_'s ipvt(k) [radex.so sgefa_,
+ * SURVEY.md A.5] expressed as rows instead of interchanges (meaningless on a singular system).
+ * Integer output: the parity bar is equality, exact ties (isamax's first-maximum rule) included. */
+int rx_lubksb_pivots_batch(rx_handle *h, int N, int n, const double *A, double *x, int32_t *pivrow);
+
 /* Kernel timing hook for bench.py: runs rx_lnprob_batch_device `reps` times
  * back-to-back on `stream`, bracketing every launch with HIP events on that
  * same stream, and returns the mean per-launch kernel time in milliseconds.  */

@@ -208,14 +208,16 @@ def escprob(tau, method=2):
     return lib().rxo_escprob(float(tau), int(method))
 
 
-def lubksb(a_colmajor: np.ndarray):
-    """a: (n,n) array interpreted as Fortran A(i,j) = a[i,j]; returns (x, info)."""
+def lubksb(a_colmajor: np.ndarray, return_ipvt: bool = False):
+    """a: (n,n) array interpreted as Fortran A(i,j) = a[i,j]; returns (x, info[, ipvt 0-based])."""
     n = a_colmajor.shape[0]
     buf = np.asfortranarray(a_colmajor, dtype=np.float64).copy(order="F")
     flat = buf.reshape(-1, order="F").copy()
     x = np.empty(n)
     ipvt = np.empty(n, dtype=np.int32)
     info = lib().rxo_lubksb(_dp(flat), n, _dp(x), ipvt.ctypes.data_as(C.POINTER(C.c_int)))
+    if return_ipvt:
+        return x, info, ipvt
     return x, info
 
 

@@ -214,7 +214,7 @@ int hip_fail(rx_handle *h, hipError_t e, const char *what)
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
 
 typedef void (*kernel_fn)(const RxKArgs);
-typedef void (*lukernel_fn)(const double *, double *, int, int);
+typedef void (*lukernel_fn)(const double *, double *, int32_t *, int, int);
 
 lukernel_fn lukernel_for(int NL)
 {
@@ -717,18 +717,26 @@ int rx_solve_batch(rx_handle *h, int src, int N, const double *tkin, const doubl
     return 0;
 }
 
-int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x)
+int rx_lubksb_pivots_batch(rx_handle *h, int N, int n, const double *A, double *x, int32_t *pivrow)
 {
     if (!h || N < 0 || n < 2 || n > h->NL || (N > 0 && (!A || !x))) return RX_E_ARG;
     if (N == 0) return 0;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, h->s_params.reserve((size_t)N * n * n));
     HIPCHK(h, h->s_lnp.reserve((size_t)N * n));
+    if (pivrow) HIPCHK(h, h->s_status.reserve((size_t)N * n));
     HIPCHK(h, hipMemcpy(h->s_params.p, A, (size_t)N * n * n * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(lukernel_for(h->NL), dim3(N), dim3(64), 0, nullptr, h->s_params.p, h->s_lnp.p, n, N);
+    hipLaunchKernelGGL(lukernel_for(h->NL), dim3(N), dim3(64), 0, nullptr, h->s_params.p, h->s_lnp.p,
+                       pivrow ? h->s_status.p : nullptr, n, N);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpy(x, h->s_lnp.p, (size_t)N * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (pivrow) HIPCHK(h, hipMemcpy(pivrow, h->s_status.p, (size_t)N * n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
+}
+
+int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x)
+{
+    return rx_lubksb_pivots_batch(h, N, n, A, x, nullptr);
 }
 
 int rx_time_lnprob_device(rx_handle *h, int N, const double *d_params, const int32_t *d_src_index,

@@ -136,15 +136,20 @@ class Engine:
                                          _ip(out["niter"])), "rx_solve_batch")
         return out
 
-    def lubksb_batch(self, A):
-        """A: [N, n, n]; returns x[N, n] (last row <- 1, rhs = e_last; see rx_lubksb_batch)."""
+    def lubksb_batch(self, A, return_pivots=False):
+        """A: [N, n, n]; returns x[N, n] (last row <- 1, rhs = e_last; see rx_lubksb_batch), and with
+        return_pivots the pivot row of every elimination step [N, n] (rx_lubksb_pivots_batch)."""
         A = np.ascontiguousarray(A, dtype=np.float64)
         if A.ndim == 2:
             A = A[None]
         N, n, _ = A.shape
         x = np.empty((N, n))
-        self._chk(self._L.rx_lubksb_batch(self._h, N, n, _dp(A), _dp(x)), "rx_lubksb_batch")
-        return x
+        if not return_pivots:
+            self._chk(self._L.rx_lubksb_batch(self._h, N, n, _dp(A), _dp(x)), "rx_lubksb_batch")
+            return x
+        piv = np.empty((N, n), dtype=np.int32)
+        self._chk(self._L.rx_lubksb_pivots_batch(self._h, N, n, _dp(A), _dp(x), _ip(piv)), "rx_lubksb_pivots_batch")
+        return x, piv
 
     # -- batched evaluation, device-resident torch tensors -------------------------------
     def lnprob_batch_torch(self, params, lnp=None, status=None, niter=None, src_index=None, stream=None):

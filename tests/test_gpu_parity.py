@@ -81,19 +81,43 @@ def test_lubksb_random_vs_oracle(engines, n, tmp_path):
         a = -rng.rand(n, n) * 10.0 ** rng.uniform(-12, 0, size=(n, n))
         a[np.arange(n), np.arange(n)] = -a.sum(axis=0) + a.diagonal()
         mats.append(a)
+    if n >= 8:
+        for _ in range(4):        # exact ties at step 0: three rows share the largest |a(i,0)|
+            a = rng.randn(n, n) * 0.3
+            a[rng.choice(n - 1, 3, replace=False), 0] = 5.0 * rng.choice([-1.0, 1.0], 3)
+            mats.append(a)
+        for _ in range(4):        # exact tie at step 1 between row 0 -- moved to position r0 by the
+            a = rng.randn(n, n) * 0.3          # interchange of step 0 -- and row 2: sgefa_ takes row 2
+            r0 = int(rng.randint(3, n - 1))    # (lower POSITION), not the lower row index
+            a[r0, 0] = 9.0
+            a[0, :2] = a[2, :2] = (0.3, 7.0)
+            mats.append(a)
     nexact = len(mats)
     for _ in range(4):                                   # exactly singular: a zero balance equation
         a = rng.randn(n, n)                              #   (stays zero through the elimination)
         a[rng.randint(0, n - 1)] = 0.0
         mats.append(a)
     A = np.array(mats)
-    x = eng.lubksb_batch(A)
+    x, piv = eng.lubksb_batch(A, return_pivots=True)
     for m, a in enumerate(mats):
-        want, info = O.lubksb(a)
+        want, info, ipvt = O.lubksb(a, return_ipvt=True)
         if m >= nexact:
             assert info != 0
             assert np.array_equal(x[m], want), (n, m, "singular system must return e_last")
             continue
+        if info == 0:
+            # integer output, bar = equality: the pivot ROW of every step (sgefa_'s ipvt replayed),
+            # exact ties between candidates included.  Where FMA contraction can flip a comparison
+            # between two nearly equal candidates the sequences may part; that needs |a|'s equal to
+            # ~1e-16, which the gaussian and rate-like draws do not produce.
+            order = list(range(n))
+            rows = []
+            for k in range(n):
+                l = int(ipvt[k]) if k < n - 1 else n - 1
+                order[k], order[l] = order[l], order[k]
+                rows.append(order[k])
+            if not (12 <= m < 24):        # (integer draws: rounding may turn a tie into a near-tie)
+                assert list(piv[m]) == rows, (n, m, list(piv[m]), rows)
         aa = a.copy()
         aa[n - 1] = 1.0
         cond = np.linalg.cond(aa)
