@@ -59,6 +59,35 @@ def test_lubksb_vs_reference_binary(engines, golden_dir):
         assert np.max(np.abs(x - want) / np.abs(want)) < 1e-10, n
 
 
+def test_pivot_choices_vs_reference_binary(engines, golden_dir, tmp_path):
+    """Pivot row of every elimination step against the ipvt of the reference's own sgefa_
+    (tests/golden/ref_sgefa.json): gaussian systems, exact ties at step 0, an exact tie at step 1
+    that sgefa_ resolves by POSITION after the interchange of step 0.  Integer output: equality.
+    (Small-integer systems are skipped: there FMA contraction can turn an exact tie of the
+    reference's arithmetic into a near-tie.)"""
+    from radex_emcee_amd.molecule import synth_co_text
+    g = json.load(open(os.path.join(golden_dir, "ref_sgefa.json")))
+    eng_by_n = {41: engines[2]}
+    checked = 0
+    for c in g["cases"]:
+        n = c["n"]
+        if c["kind"] == "int" or c["info"] != 0:
+            continue
+        if n not in eng_by_n:
+            path = tmp_path / ("rotor%d.dat" % n)
+            path.write_text(synth_co_text(nlev=n))
+            eng_by_n[n] = Engine(str(path))
+        _x, piv = eng_by_n[n].lubksb_batch(np.array(c["A"]).reshape(n, n), return_pivots=True)
+        order, rows = list(range(n)), []
+        for k in range(n):
+            l = c["ipvt"][k] if k < n - 1 else n - 1
+            order[k], order[l] = order[l], order[k]
+            rows.append(order[k])
+        assert list(piv[0]) == rows, (c["kind"], n)
+        checked += 1
+    assert checked >= 20
+
+
 @pytest.mark.parametrize("n", [3, 8, 9, 20, 21, 32, 41, 45, 48, 64])
 def test_lubksb_random_vs_oracle(engines, n, tmp_path):
     """The LU alone on matrices that are nothing like a rate matrix: an interchange at almost every
