@@ -1,3 +1,4 @@
+"""Diagnostic: iteration counts near the truth, host-call vs kernel time, and a profile of the sampler loop."""
 import sys, time; sys.path.insert(0,'.')
 import numpy as np, torch
 from radex_emcee_amd import workloads
