@@ -52,6 +52,16 @@ TEST(k_f24, F12 F12, 24)
               "v_cmp_ne_u32 vcc, 48, %5\n\tv_cndmask_b32 %5, 0, %5, vcc\n\tv_cndmask_b32 %5, 0, %5, vcc\n\ts_cmp_eq_u32 s40, 0\n\ts_cbranch_scc0 1f\n1:\n\t"
 TEST(k_chain, CHAIN, 1)
 
+TEST(k_mix_3dpp_1fmac, DPPF("%0", "%4", "%3", "5") DPPF("%1", "%4", "%3", "5") DPPF("%2", "%4", "%3", "5") "v_fmac_f64 %4, %3, %3\n\t", 4)
+TEST(k_mix_3dpp_1nop, DPPF("%0", "%4", "%3", "5") DPPF("%1", "%4", "%3", "5") DPPF("%2", "%4", "%3", "5") "s_nop 0\n\t", 4)
+TEST(k_mix_2dpp_1fmac, DPPF("%0", "%4", "%3", "5") DPPF("%1", "%4", "%3", "5") "v_fmac_f64 %2, %3, %3\n\t", 3)
+TEST(k_mix_mul_fmac, "v_mul_f64 %0, %4, %3\n\tv_fmac_f64 %1, %3, %3\n\t", 2)
+TEST(k_mix_mul_nop, "v_mul_f64 %0, %4, %3\n\ts_nop 0\n\t", 2)
+TEST(k_snop, "s_nop 0\n\t", 1)
+TEST(k_salu4, "s_or_b32 s40, s41, s42\n\t", 1)
+TEST(k_salu8, "s_and_b32 s40, s41, 0xff80\n\t", 1)
+TEST(k_mix_mul_salu, "v_mul_f64 %0, %4, %3\n\ts_or_b32 s40, s41, s42\n\t", 2)
+
 __global__ void k_sem(double *out)
 {
     const int lane = threadIdx.x;
@@ -70,10 +80,13 @@ __global__ void k_sem(double *out)
     hipEventRecord(e0); hipLaunchKernelGGL(NAME, dim3(1), dim3(64), 0, 0, d_out, d_sink, 3); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); \
     hipMemcpy(&h, d_out, 8, hipMemcpyDeviceToHost); \
     printf("%-20s %8.2f ticks per %g instr = %6.2f /instr   (kernel %.3f ms incl. launch, %.0f ticks/us)\n", #NAME, (double)h / (100.0 * 64.0), NAME##_per, (double)h / (100.0 * 64.0 * NAME##_per), ms, (double)h / (ms * 1e3)); } while (0)
+#define RUN8(NAME) do { hipLaunchKernelGGL(NAME, dim3(1), dim3(512), 0, 0, d_out, d_sink, 3); hipDeviceSynchronize(); \
+    hipMemcpy(&h, d_out, 8, hipMemcpyDeviceToHost); \
+    printf("%-20s 8 waves in the workgroup (2 per SIMD): %6.2f ticks/instr for wave 0\n", #NAME, (double)h / (100.0 * 64.0 * NAME##_per)); } while (0)
 int main()
 {
     unsigned long long *d_out, h; double *d_sink; hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipMalloc(&d_out, 8); hipMalloc(&d_sink, 64 * 8); hipMemset(d_sink, 0, 64 * 8);
+    hipMalloc(&d_out, 8); hipMalloc(&d_sink, 512 * 8); hipMemset(d_sink, 0, 512 * 8);
     double *d_sem, hs[192]; hipMalloc(&d_sem, sizeof(hs));
     hipLaunchKernelGGL(k_sem, dim3(1), dim3(64), 0, 0, d_sem); hipMemcpy(hs, d_sem, sizeof(hs), hipMemcpyDeviceToHost);
     int bad = 0;
@@ -86,5 +99,7 @@ int main()
     printf("semantics: fmac_dpp/mov_dpp/row_mask %s (mask %d)  sample: lane 37 -> %.1f, %.1f, %.1f\n", bad ? "UNEXPECTED" : "as expected", bad, hs[37], hs[64 + 37], hs[128 + 37]);
     RUN(k_fmac_plain); RUN(k_fmac_plain); RUN(k_fmac_dpp); RUN(k_fmac_dpp_dep); RUN(k_fmac_dpp_selfsrc); RUN(k_mov64_dpp); RUN(k_mov64); RUN(k_mul64); RUN(k_cmp64);
     RUN(k_read2_b64); RUN(k_read_b128); RUN(k_read_b64); RUN(k_write_b128); RUN(k_write_b64_uni); RUN(k_bcast_rt); RUN(k_bcast_hidden); RUN(k_f24); RUN(k_chain);
+    RUN(k_mix_3dpp_1fmac); RUN(k_mix_3dpp_1nop); RUN(k_mix_2dpp_1fmac); RUN(k_mix_mul_fmac); RUN(k_mix_mul_nop); RUN(k_snop); RUN(k_salu4); RUN(k_salu8); RUN(k_mix_mul_salu);
+    RUN8(k_mul64); RUN8(k_fmac_dpp); RUN8(k_mix_mul_salu);
     return 0;
 }
