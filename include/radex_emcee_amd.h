@@ -153,6 +153,14 @@ int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x);
  * Integer output: the parity bar is equality, exact ties (isamax's first-maximum rule) included. */
 int rx_lubksb_pivots_batch(rx_handle *h, int N, int n, const double *A, double *x, int32_t *pivrow);
 
+/* Replaces escprob_(tau) (radex.so@0xa9c0; called 40x per iteration from
+ * matrix_): beta[N] = escape probability of tau[N] for geometry `method` (1 sphere, 2 lvg,
+ * 3 slab), evaluated by the device routine the solve kernel uses.  Host pointers.  Exposed so the
+ * routine can be checked on its own against the reference binary's escprob_ vectors.
+ * method = 0 evaluates the kernel's natural logarithm instead (the LVG branch and the excitation
+ * temperatures use it in place of the library's): y = log(x), special operands as libm.        */
+int rx_escprob_batch(rx_handle *h, int method, int N, const double *tau, double *beta);
+
 /* Kernel timing hook for bench.py: runs rx_lnprob_batch_device `reps` times
  * back-to-back on `stream`, bracketing every launch with HIP events on that
  * same stream, and returns the mean per-launch kernel time in milliseconds.  */

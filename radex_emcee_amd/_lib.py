@@ -22,7 +22,7 @@ EXPORTS = [
     "rx_abi_version", "rx_create", "rx_destroy", "rx_last_error", "rx_nlev", "rx_nline",
     "rx_npart", "rx_partner_ids", "rx_line_data", "rx_set_fortho", "rx_set_iteration_limits",
     "rx_set_source", "rx_lnprob_batch", "rx_lnprob_batch_device", "rx_model_flux_batch",
-    "rx_model_flux_batch_device", "rx_solve_batch", "rx_lubksb_batch", "rx_lubksb_pivots_batch", "rx_time_lnprob_device",
+    "rx_model_flux_batch_device", "rx_solve_batch", "rx_lubksb_batch", "rx_lubksb_pivots_batch", "rx_escprob_batch", "rx_time_lnprob_device",
     "rx_kernel_name",
 ]
 
@@ -86,6 +86,7 @@ def load():
     L.rx_solve_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip]
     L.rx_lubksb_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.rx_lubksb_pivots_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip]
+    L.rx_escprob_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.rx_time_lnprob_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
     _lib = L
     return L

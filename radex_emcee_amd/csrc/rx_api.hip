@@ -734,6 +734,20 @@ int rx_lubksb_pivots_batch(rx_handle *h, int N, int n, const double *A, double *
     return 0;
 }
 
+int rx_escprob_batch(rx_handle *h, int method, int N, const double *tau, double *beta)
+{
+    if (!h || N < 0 || method < 0 || method > 3 || (N > 0 && (!tau || !beta))) return RX_E_ARG;
+    if (N == 0) return 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, h->s_params.reserve((size_t)N));
+    HIPCHK(h, h->s_lnp.reserve((size_t)N));
+    HIPCHK(h, hipMemcpy(h->s_params.p, tau, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rxk::rx_escprob_kernel, dim3((N + 63) / 64), dim3(64), 0, nullptr, h->s_params.p, h->s_lnp.p, method, N);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpy(beta, h->s_lnp.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x)
 {
     return rx_lubksb_pivots_batch(h, N, n, A, x, nullptr);

@@ -151,6 +151,14 @@ class Engine:
         self._chk(self._L.rx_lubksb_pivots_batch(self._h, N, n, _dp(A), _dp(x), _ip(piv)), "rx_lubksb_pivots_batch")
         return x, piv
 
+    def escprob_batch(self, tau, method=2):
+        """beta(tau) of the device escprob_ for geometry `method` (1 sphere, 2 lvg, 3 slab); method 0:
+        the kernel's natural logarithm (rx_escprob_batch)."""
+        tau = np.ascontiguousarray(tau, dtype=np.float64).ravel()
+        out = np.empty_like(tau)
+        self._chk(self._L.rx_escprob_batch(self._h, int(method), len(tau), _dp(tau), _dp(out)), "rx_escprob_batch")
+        return out
+
     # -- batched evaluation, device-resident torch tensors -------------------------------
     def lnprob_batch_torch(self, params, lnp=None, status=None, niter=None, src_index=None, stream=None):
         """params: CUDA float64 tensor [N, ndim] on this engine's device; asynchronous on `stream`."""

@@ -59,6 +59,40 @@ def test_lubksb_vs_reference_binary(engines, golden_dir):
         assert np.max(np.abs(x - want) / np.abs(want)) < 1e-10, n
 
 
+def test_escprob_vs_reference_binary(engines, golden_dir):
+    """The device escprob_ against the 88 values the reference binary's own escprob_ returned
+    (sphere / LVG / slab, the branch boundaries, the NaN of the LVG maser branch)."""
+    g = json.load(open(os.path.join(golden_dir, "ref_escprob.json")))
+    for method in (1, 2, 3):
+        cs = [c for c in g["cases"] if c["method"] == method]
+        tau = np.array([c["tau"] for c in cs])
+        want = np.array([np.nan if c["beta"] is None else c["beta"] for c in cs], dtype=float)
+        got = engines[2].escprob_batch(tau, method)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), method
+        f = ~np.isnan(want)
+        # OCML exp / the kernel's log against the binary's libm: 1 ulp of exp(-x), amplified by the
+        # cancellation in 1 - exp(-x) near the branch boundaries (x ~ 0.02: x100)
+        dev = np.abs(got[f] - want[f]) / np.abs(want[f])
+        assert dev.max() < 2e-13, (method, tau[f][np.argmax(dev)], dev.max())
+        assert np.median(dev) < 3e-16, method
+
+
+def test_kernel_logarithm(engines):
+    """rx_log (plain-double argument reduction + polynomial, used by the LVG escape probability and the
+    excitation temperatures): <= 2 ulp from libm over the whole range, special operands as libm."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([10.0 ** rng.uniform(-300, 300, 20000), rng.uniform(0.5, 2.0, 20000),
+                        1.0 + rng.uniform(-1e-3, 1e-3, 5000), np.array([1.0, 2.0, 0.5, 4.9e-324, 2.2e-308, 1.7e308])])
+    got = engines[2].escprob_batch(x, 0)
+    want = np.log(x)
+    ulp = np.abs(got - want) / np.spacing(np.abs(want) + 5e-324)
+    assert ulp.max() <= 2.0, (ulp.max(), x[np.argmax(ulp)])
+    with np.errstate(all="ignore"):
+        sp = np.array([0.0, -0.0, -1.0, -1e-300, np.inf, np.nan])
+        g2 = engines[2].escprob_batch(sp, 0)
+    assert g2[0] == -np.inf and g2[1] == -np.inf and np.isnan(g2[2]) and np.isnan(g2[3]) and g2[4] == np.inf and np.isnan(g2[5])
+
+
 def test_pivot_choices_vs_reference_binary(engines, golden_dir, tmp_path):
     """Pivot row of every elimination step against the ipvt of the reference's own sgefa_
     (tests/golden/ref_sgefa.json): gaussian systems, exact ties at step 0, an exact tie at step 1
