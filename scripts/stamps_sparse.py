@@ -9,6 +9,8 @@ r = e.solve_batch(10 ** W[:, 1], 10 ** W[:, 2], np.stack([0.25 * n, 0.75 * n], 1
 d = np.fromfile("/tmp/stamps.bin").reshape(1024, 64)
 slots = [int(x) for x in sys.argv[2].split(",")]
 ok = np.all(np.isfinite(d[:, slots]), axis=1) & (d[:, slots[-1]] > d[:, slots[0]])
+if len(sys.argv) > 3 and sys.argv[3] == "slow":       # only the walkers that run into maxiter (they set the launch time)
+    ok &= np.asarray(r["niter"]) >= 200
 print("%d of %d walkers carry stamps" % (ok.sum(), len(d)))
 for a, b in zip(slots[:-1], slots[1:]):
     print("slot %d -> %d: median %.0f ticks" % (a, b, np.median(d[ok, b] - d[ok, a])))
