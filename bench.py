@@ -205,6 +205,30 @@ def main():
             msL = eng.time_lnprob_torch(PL, *oL, reps=5, stream=stream)
             out["large_batch"] = {"walkers": 32768, "kernel_ms": round(msL, 3),
                                   "value": round(32768 / (msL * 1e-3), 1), "unit": "evals/s"}
+        if world == 1 and args.walkers == 1024 and not args.no_large_batch:
+            # two INDEPENDENT 1024-walker ensembles (two handles, two streams) in flight together: not the
+            # headline either -- one ensemble's steps depend on each other -- but what multi-chain runs
+            # see: four fifths of a 1024-walker launch is the tail of its never-converging walkers, which
+            # keeps ~23 of the 256 CUs busy; the other ensemble's workgroups run on the CUs that are free
+            eng2 = Engine(device=local)
+            eng2.set_source(cfg["tbg"], cfg["Jup"], truth_flux, 0.1 * truth_flux, cfg["bounds"])
+            cfg2 = workloads.config2(args.walkers, seed=4321)
+            P2 = torch.from_numpy(cfg2["walkers"]).to(dev)
+            o2 = [torch.empty(args.walkers, dtype=t, device=dev) for t in (torch.float64, torch.int32, torch.int32)]
+            s2 = torch.cuda.Stream(device=dev)
+            reps2 = max(5, min(50, args.steps))
+            eng2.lnprob_batch_torch(P2, *o2, stream=s2.cuda_stream)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(reps2):
+                eng.lnprob_batch_torch(P, lnp, st, nit, stream=stream)
+                eng2.lnprob_batch_torch(P2, *o2, stream=s2.cuda_stream)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t2
+            out["two_ensembles"] = {"walkers": [args.walkers, args.walkers], "ms_per_pair_of_launches": round(d2 / reps2 * 1e3, 4),
+                                    "value": round(2 * args.walkers * reps2 / d2, 1), "unit": "evals/s",
+                                    "note": "two handles on two HIP streams, independent ensembles; wall time"}
+            eng2.close()
         if world == 1 and not args.no_sampler:
             # the caller of the path: stretch-move chain, walkers in a ball around the
             # truth like emcee_radex.py:477, two half-ensemble launches per step, host buffers
