@@ -24,7 +24,7 @@ def build_asm():
     d = tempfile.mkdtemp(prefix="rxasm")
     src = os.path.join(ROOT, "radex_emcee_amd", "csrc", "rx_api.hip")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
-           "-mllvm", "-pragma-unroll-threshold=4000000", "-save-temps", "-c", "-o", "/dev/null", src] + sys.argv[2:]
+           "-mllvm", "-pragma-unroll-threshold=4000000", "-mllvm", "-disable-machine-licm", "-save-temps", "-c", "-o", "/dev/null", src] + sys.argv[2:]
     subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return os.path.join(d, "rx_api-hip-amdgcn-amd-amdhsa-gfx950.s")
 
