@@ -198,7 +198,8 @@ struct rx_handle {
     int num_cu = 256, blocks_per_cu2 = 1;
     // staging for the host-pointer API + 2-component scratch
     DevBuf<double> s_params, s_lnp, s_flux, s_cflux, s_in3, s_dens, s_xpop, s_tex, s_tau, s_sb;
-    DevBuf<int32_t> s_src, s_status, s_niter, s_cstatus, s_cniter, s_srcfix;
+    DevBuf<int32_t> s_src, s_status, s_niter, s_cstatus, s_cniter, s_srcfix, s_order;
+    unsigned int *d_order_cnt = nullptr;
     int srcfix_value = -1;
     size_t srcfix_filled = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -407,6 +408,18 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     kernel_fn k = kernel_for(h->NL, occ, h->mol.nlev == h->NL);
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
     if (e0) HIPCHK(h, hipEventRecord(e0, st));
+    // more items than resident wavefronts: hand the walkers out hottest first (see rx_order_bucket)
+    a.order = nullptr;
+    if (items > 2 * cap * RXK_WAVES_PER_BLOCK && !getenv("RX_NO_ORDER")) {
+        HIPCHK(h, h->s_order.reserve((size_t)a.N));
+        a.order_out = h->s_order.p;
+        a.order_cnt = h->d_order_cnt;
+        HIPCHK(h, hipMemsetAsync(h->d_order_cnt, 0, 2 * RXK_ORDER_BUCKETS * sizeof(unsigned int), st));
+        const int tb = 256, nb = (a.N + tb - 1) / tb;
+        hipLaunchKernelGGL(rxk::rx_order_count_kernel, dim3(nb), dim3(tb), 0, st, a);
+        hipLaunchKernelGGL(rxk::rx_order_scatter_kernel, dim3(nb), dim3(tb), 0, st, a);
+        a.order = h->s_order.p;
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, a);
     if (ncomp == 2) {
         const int tb = 256;
@@ -477,6 +490,7 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipMalloc(&h->d_srcs, sizeof(RxSourceDev) * RX_MAX_SOURCES)) != hipSuccess) return hipfail("hipMalloc", e);
     if ((e = hipMemset(h->d_srcs, 0, sizeof(RxSourceDev) * RX_MAX_SOURCES)) != hipSuccess) return hipfail("hipMemset", e);
     if ((e = hipMalloc(&h->d_queue, sizeof(unsigned int))) != hipSuccess) return hipfail("hipMalloc", e);
+    if ((e = hipMalloc(&h->d_order_cnt, 2 * RXK_ORDER_BUCKETS * sizeof(unsigned int))) != hipSuccess) return hipfail("hipMalloc", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
     int nb = 0;
@@ -496,6 +510,7 @@ void rx_destroy(rx_handle *h)
     for (double *p : h->d_ksym) (void)hipFree(p);
     if (h->d_srcs) (void)hipFree(h->d_srcs);
     if (h->d_queue) (void)hipFree(h->d_queue);
+    if (h->d_order_cnt) (void)hipFree(h->d_order_cnt);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     h->s_params.release(); h->s_lnp.release(); h->s_flux.release(); h->s_cflux.release();

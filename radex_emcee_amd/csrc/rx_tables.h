@@ -8,6 +8,7 @@
 #define RXK_MAXLEV 64
 #define RXK_MAXNJ 32
 #define RXK_MAXSRC 64
+#define RXK_ORDER_BUCKETS 32
 #define RXK_WAVES_PER_BLOCK 4  // one workgroup = 4 wavefronts = 4 walkers in flight, 1 per SIMD
 
 // Per-line constants.  Everything here is a pure function of the molecular
@@ -83,6 +84,10 @@ struct RxKArgs {
     const double *tkin, *cdmol, *dens;
     // work queue: one counter, zeroed by a memset node before every launch
     unsigned int *queue;
+    // optional issue order of the walkers (hottest first, rx_order_*_kernel): order[N], or null = 0..N-1
+    const int32_t *order;
+    int32_t *order_out;             // order kernels only
+    unsigned int *order_cnt;        // order kernels only: [2][RXK_ORDER_BUCKETS] counters, zeroed before them
     // outputs
     double *lnp;                    // [N]
     int32_t *status, *niter;        // [N]

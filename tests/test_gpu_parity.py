@@ -414,6 +414,20 @@ def test_full_size_properties(engines, mol):
     assert np.max(np.abs(an[pick][fin] - rl[fin]) / np.maximum(np.abs(rl[fin]), 1.0)) < 1e-6
 
 
+def test_issue_order_changes_no_result(engines, mol, monkeypatch):
+    """Batches larger than the resident wavefronts are handed out hottest walkers first
+    (rx_order_*_kernel): a scheduling decision -- every output must be bit-identical without it."""
+    eng = engines[2]
+    cfg = workloads.config2(6000, seed=77)
+    src = _truth_source(eng, mol, cfg)
+    lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True)
+    monkeypatch.setenv("RX_NO_ORDER", "1")
+    lnp0, st0, nit0 = eng.lnprob_batch(cfg["walkers"], return_info=True)
+    assert np.array_equal(st, st0) and np.array_equal(nit, nit0)
+    assert np.array_equal(lnp, lnp0, equal_nan=True)
+    assert (st == 1).sum() > 0
+
+
 def test_device_pointer_api_on_side_stream(engines, mol):
     import torch
     eng = engines[2]
