@@ -62,6 +62,22 @@ TEST(k_salu4, "s_or_b32 s40, s41, s42\n\t", 1)
 TEST(k_salu8, "s_and_b32 s40, s41, 0xff80\n\t", 1)
 TEST(k_mix_mul_salu, "v_mul_f64 %0, %4, %3\n\ts_or_b32 s40, s41, s42\n\t", 2)
 
+TEST(k_rcp64, "v_rcp_f64 %0, %4\n\tv_rcp_f64 %1, %4\n\t", 2)
+TEST(k_rsq64, "v_rsq_f64 %0, %4\n\tv_rsq_f64 %1, %4\n\t", 2)
+TEST(k_ldexp64, "v_ldexp_f64 %0, %4, %5\n\tv_ldexp_f64 %1, %4, %5\n\t", 2)
+TEST(k_frexp64, "v_frexp_mant_f64 %0, %4\n\tv_frexp_mant_f64 %1, %4\n\t", 2)
+TEST(k_divfmas, "v_div_fmas_f64 %0, %4, %3, %2\n\tv_div_fmas_f64 %1, %4, %3, %2\n\t", 2)
+TEST(k_divfixup, "v_div_fixup_f64 %0, %4, %3, %2\n\tv_div_fixup_f64 %1, %4, %3, %2\n\t", 2)
+TEST(k_divscale, "v_div_scale_f64 %0, vcc, %4, %3, %4\n\tv_div_scale_f64 %1, vcc, %4, %3, %4\n\t", 2)
+TEST(k_cvt_f64_i32, "v_cvt_f64_i32 %0, %5\n\tv_cvt_f64_i32 %1, %5\n\t", 2)
+TEST(k_fma_dep1, "v_fma_f64 %0, %0, %4, %3\n\t", 1)
+TEST(k_fma_dep_mix, "v_fma_f64 %0, %0, %4, %3\n\tv_fma_f64 %1, %1, %4, %3\n\t", 2)
+TEST(k_cmp_cnd, "v_cmp_gt_f64 vcc, %4, %3\n\tv_cndmask_b32 %5, %5, %5, vcc\n\t", 2)
+TEST(k_rdlane_salu, "v_readlane_b32 s40, %5, 3\n\ts_add_u32 s41, s40, 1\n\t", 2)
+TEST(k_accread, "v_accvgpr_read_b32 %5, a0\n\t", 1)
+TEST(k_add64, "v_add_f64 %0, %4, %3\n\tv_add_f64 %1, %4, %3\n\t", 2)
+TEST(k_add_dep, "v_add_f64 %0, %0, %3\n\t", 1)
+
 __global__ void k_sem(double *out)
 {
     const int lane = threadIdx.x;
@@ -100,6 +116,7 @@ int main()
     RUN(k_fmac_plain); RUN(k_fmac_plain); RUN(k_fmac_dpp); RUN(k_fmac_dpp_dep); RUN(k_fmac_dpp_selfsrc); RUN(k_mov64_dpp); RUN(k_mov64); RUN(k_mul64); RUN(k_cmp64);
     RUN(k_read2_b64); RUN(k_read_b128); RUN(k_read_b64); RUN(k_write_b128); RUN(k_write_b64_uni); RUN(k_bcast_rt); RUN(k_bcast_hidden); RUN(k_f24); RUN(k_chain);
     RUN(k_mix_3dpp_1fmac); RUN(k_mix_3dpp_1nop); RUN(k_mix_2dpp_1fmac); RUN(k_mix_mul_fmac); RUN(k_mix_mul_nop); RUN(k_snop); RUN(k_salu4); RUN(k_salu8); RUN(k_mix_mul_salu);
+    RUN(k_rcp64); RUN(k_rsq64); RUN(k_ldexp64); RUN(k_frexp64); RUN(k_divfmas); RUN(k_divfixup); RUN(k_divscale); RUN(k_cvt_f64_i32); RUN(k_fma_dep1); RUN(k_fma_dep_mix); RUN(k_cmp_cnd); RUN(k_rdlane_salu); RUN(k_accread); RUN(k_add64); RUN(k_add_dep);
     RUN8(k_mul64); RUN8(k_fmac_dpp); RUN8(k_mix_mul_salu);
     return 0;
 }
