@@ -78,6 +78,13 @@ TEST(k_accread, "v_accvgpr_read_b32 %5, a0\n\t", 1)
 TEST(k_add64, "v_add_f64 %0, %4, %3\n\tv_add_f64 %1, %4, %3\n\t", 2)
 TEST(k_add_dep, "v_add_f64 %0, %0, %3\n\t", 1)
 
+TEST(k_br_scc0_nt, "s_cmp_eq_u32 s40, s40\n\ts_cbranch_scc0 1f\n\tv_fmac_f64 %0, %4, %3\n1:\n\t", 3)
+TEST(k_br_scc1_nt, "s_cmp_lg_u32 s40, s40\n\ts_cbranch_scc1 1f\n\tv_fmac_f64 %0, %4, %3\n1:\n\t", 3)
+TEST(k_br_vccnz_nt, "s_cbranch_vccnz 1f\n\tv_fmac_f64 %0, %4, %3\n1:\n\t", 2)
+TEST(k_br_execz_nt, "s_cbranch_execz 1f\n\tv_fmac_f64 %0, %4, %3\n1:\n\t", 2)
+TEST(k_br_taken, "s_cmp_eq_u32 s40, s40\n\ts_cbranch_scc1 1f\n\tv_fmac_f64 %0, %4, %3\n1:\n\t", 2)
+TEST(k_nobr, "s_cmp_eq_u32 s40, s40\n\tv_fmac_f64 %0, %4, %3\n\t", 2)
+
 __global__ void k_sem(double *out)
 {
     const int lane = threadIdx.x;
@@ -117,6 +124,7 @@ int main()
     RUN(k_read2_b64); RUN(k_read_b128); RUN(k_read_b64); RUN(k_write_b128); RUN(k_write_b64_uni); RUN(k_bcast_rt); RUN(k_bcast_hidden); RUN(k_f24); RUN(k_chain);
     RUN(k_mix_3dpp_1fmac); RUN(k_mix_3dpp_1nop); RUN(k_mix_2dpp_1fmac); RUN(k_mix_mul_fmac); RUN(k_mix_mul_nop); RUN(k_snop); RUN(k_salu4); RUN(k_salu8); RUN(k_mix_mul_salu);
     RUN(k_rcp64); RUN(k_rsq64); RUN(k_ldexp64); RUN(k_frexp64); RUN(k_divfmas); RUN(k_divfixup); RUN(k_divscale); RUN(k_cvt_f64_i32); RUN(k_fma_dep1); RUN(k_fma_dep_mix); RUN(k_cmp_cnd); RUN(k_rdlane_salu); RUN(k_accread); RUN(k_add64); RUN(k_add_dep);
+    RUN(k_br_scc0_nt); RUN(k_br_scc1_nt); RUN(k_br_vccnz_nt); RUN(k_br_execz_nt); RUN(k_br_taken); RUN(k_nobr);
     RUN8(k_mul64); RUN8(k_fmac_dpp); RUN8(k_mix_mul_salu);
     return 0;
 }
