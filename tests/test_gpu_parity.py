@@ -428,6 +428,33 @@ def test_issue_order_changes_no_result(engines, mol, monkeypatch):
     assert (st == 1).sum() > 0
 
 
+def test_two_handles_on_two_streams(engines, mol):
+    """The ABI allows several handles to be used concurrently (one per source / per chain): two engines,
+    two HIP streams, launches in flight together -- each must return what it returns alone."""
+    import torch
+    from radex_emcee_amd.engine import Engine
+    eng = engines[2]
+    cfgA, cfgB = workloads.config2(1024, seed=11), workloads.config2(1024, seed=12)
+    _truth_source(eng, mol, cfgA)
+    dev = torch.device("cuda:0")
+    PA, PB = (torch.from_numpy(c["walkers"]).to(dev) for c in (cfgA, cfgB))
+    refA = [t.clone() for t in eng.lnprob_batch_torch(PA)]
+    refB = [t.clone() for t in eng.lnprob_batch_torch(PB)]
+    torch.cuda.synchronize()
+    eng2 = Engine(eng.molfile)
+    src = _truth_source(eng2, mol, cfgA)
+    sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outA = [torch.empty(1024, dtype=t, device=dev) for t in (torch.float64, torch.int32, torch.int32)]
+    outB = [torch.empty(1024, dtype=t, device=dev) for t in (torch.float64, torch.int32, torch.int32)]
+    for _ in range(5):
+        eng.lnprob_batch_torch(PA, *outA, stream=sA.cuda_stream)
+        eng2.lnprob_batch_torch(PB, *outB, stream=sB.cuda_stream)
+    torch.cuda.synchronize()
+    for got, want in zip(outA + outB, refA + refB):
+        assert torch.equal(got, want) or (got.dtype == torch.float64 and torch.equal(torch.nan_to_num(got, neginf=-1e308), torch.nan_to_num(want, neginf=-1e308)))
+    eng2.close()
+
+
 def test_device_pointer_api_on_side_stream(engines, mol):
     import torch
     eng = engines[2]
