@@ -253,8 +253,8 @@ int build_tables(rx_handle *h)
     for (const Partner &P : m.parts) if (P.id == 1) h->h2_total = 1;
 
     RxLevTab LV;
-    for (int i = 0; i < RXK_MAXLEV; ++i) { LV.eterm[i] = 0.0; LV.gstat[i] = 1.0; }
-    for (int i = 0; i < m.nlev; ++i) { LV.eterm[i] = m.eterm[i]; LV.gstat[i] = m.gstat[i]; }
+    for (int i = 0; i < RXK_MAXLEV; ++i) { LV.eterm[i] = 0.0; LV.gstat[i] = 1.0; LV.rgstat[i] = 1.0; }
+    for (int i = 0; i < m.nlev; ++i) { LV.eterm[i] = m.eterm[i]; LV.gstat[i] = m.gstat[i]; LV.rgstat[i] = 1.0 / m.gstat[i]; }
     RxLineTab LT;
     memset(&LT, 0, sizeof LT);
     for (int l = 0; l < RXK_MAXLINES; ++l) { LT.gm[l] = LT.gn[l] = 1.0; LT.aein[l] = 1.0; LT.fgxta[l] = 1.0; LT.thcxt[l] = 1.0; LT.rgn[l] = LT.rfgxta[l] = LT.rthcxt[l] = 1.0; }

@@ -41,6 +41,7 @@ struct RxIncTab {
 struct RxLevTab {
     double eterm[RXK_MAXLEV];       // cm^-1 (padding levels: 0)
     double gstat[RXK_MAXLEV];       // (padding levels: 1)
+    double rgstat[RXK_MAXLEV];      // 1/gstat, correctly rounded on the host (the device divides through it)
 };
 
 struct RxMolDev {
