@@ -17,7 +17,12 @@
  *     never throw; rx_last_error() gives the message;
  *   - there is NO CPU fallback: every compute entry point needs a HIP device
  *     and fails with RX_E_NODEVICE otherwise;
- *   - a handle is single-caller; use one handle per GPU / per thread.
+ *   - a handle is single-caller (one host thread at a time); use one handle per GPU / per
+ *     thread.  The *_device entry points are asynchronous on the stream they are given; the
+ *     handle owns its work queue and scratch, so its launches never overlap: a launch on
+ *     another stream than the previous one is ordered behind it with an event
+ *     (hipStreamWaitEvent), and rx_set_source waits for whatever is still running.  Launches
+ *     of DIFFERENT handles on different streams do overlap.
  */
 #ifndef RADEX_EMCEE_AMD_H
 #define RADEX_EMCEE_AMD_H
@@ -29,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 1
+#define RX_ABI_VERSION 2
 #define RX_MAX_SOURCES 64      /* sources resident in one handle (config 3: 16) */
 #define RX_MAX_NJ      32      /* observed lines per source                     */
 #define RX_MAX_LEVELS  64      /* one level per lane of a 64-wide wavefront     */
@@ -112,10 +117,56 @@ int rx_lnprob_batch(rx_handle *h, int N, const double *params,
                     const int32_t *src_index, double *lnp, int32_t *status,
                     int32_t *niter);
 /* Device-pointer form: all pointers are HIP device pointers on the handle's
- * device, `stream` is a hipStream_t (NULL = default stream); asynchronous.  */
-int rx_lnprob_batch_device(rx_handle *h, int N, const double *d_params,
+ * device, `stream` is a hipStream_t (NULL = default stream); asynchronous.
+ *   ncomp        components per walker (params is [N][4*ncomp]); stated by the caller because
+ *                the host cannot see a device-side index.  With d_src_index == NULL slot 0 must
+ *                be set with that ncomp (checked, RX_E_STATE / RX_E_ARG).
+ *   d_src_index  per-walker slot; a walker whose slot is outside 0..RX_MAX_SOURCES-1, was
+ *                never set, or holds a source of another ncomp gets lnp = -inf and status
+ *                RX_INVALID (no slot is substituted).                                     */
+int rx_lnprob_batch_device(rx_handle *h, int N, int ncomp, const double *d_params,
                            const int32_t *d_src_index, double *d_lnp,
                            int32_t *d_status, int32_t *d_niter, void *stream);
+
+/* Scheduling only: batches larger than twice the resident wavefronts are handed out hottest
+ * walkers first (the ones that run into maxiter).  Results are bit-identical
+ * either way.  Default on; the environment variable RX_NO_ORDER=1, read once by rx_create,
+ * starts a handle with it off.                                                             */
+int rx_set_issue_order(rx_handle *h, int hottest_first);
+
+/* The caller of lnprob on the device: emcee's StretchMove (a = 2) inside RedBlueMove with two
+ * random halves, as driven by EnsembleSampler.run_mcmc in emcee/emcee_radex.py:483-499 and
+ * emcee/emcee_radex_2comp.py:557-574.  Walker positions, log-probabilities and the random stream
+ * stay in HBM; nothing crosses PCIe per step.  `nens` independent ensembles of `nwalkers` walkers
+ * (even) advance together, coords is [nens*nwalkers][ndim], ensemble-major.  Random numbers are
+ * counter based (Philox4x32-10 keyed by `seed`, counter = proposal, ensemble, step, purpose):
+ * bit-reproducible per seed and identical on every rank of a multi-GPU run.
+ *
+ * rx_stretch_propose_device: half-step `split` (0/1) of step `step`: for each of the
+ *   nens*nwalkers/2 proposals t: walker s = widx[t] of this half, partner c uniform from the other
+ *   half, z = ((a-1)u+1)^2/a, q[t] = c - (c - s) z, factor[t] = (ndim-1) ln z; qsrc[t] (optional)
+ *   = ens_src[ensemble] for rx_lnprob_batch_device's d_src_index.
+ * rx_stretch_accept_device: accept q[t] iff ln u' < factor[t] + lnp_q[t] - lnp[widx[t]]
+ *   (a NaN difference, -inf - -inf, rejects, as in emcee); updates coords, lnp, naccept.
+ * rx_sampler_run_device: nsteps full steps (propose, rx_lnprob_batch_device over the proposals,
+ *   accept; twice per step) enqueued on `stream`; d_lnp must hold the log-probabilities of
+ *   d_coords on entry; d_chain [nsteps][nens*nwalkers][ndim] and d_chain_lnp
+ *   [nsteps][nens*nwalkers] (each optional) receive the state after every step
+ *   (get_chain / get_log_prob); d_ens_src [nens] = source slot per ensemble or NULL = slot 0.
+ *   Asynchronous.                                                                          */
+int rx_stretch_propose_device(rx_handle *h, int nens, int nwalkers, int ndim, double a,
+                              uint64_t seed, int64_t step, int split,
+                              const int32_t *d_ens_src, const double *d_coords, double *d_q,
+                              double *d_factor, int32_t *d_widx, int32_t *d_qsrc, void *stream);
+int rx_stretch_accept_device(rx_handle *h, int nens, int nwalkers, int ndim, uint64_t seed,
+                             int64_t step, int split, const double *d_q,
+                             const double *d_lnp_q, const double *d_factor,
+                             const int32_t *d_widx, double *d_coords, double *d_lnp,
+                             int32_t *d_naccept, void *stream);
+int rx_sampler_run_device(rx_handle *h, int nens, int nwalkers, int ncomp, double a,
+                          uint64_t seed, int64_t step0, int nsteps, const int32_t *d_ens_src,
+                          double *d_coords, double *d_lnp, int32_t *d_naccept, double *d_chain,
+                          double *d_chain_lnp, void *stream);
 
 /* Replaces model_lvg(Jup, p, R) (emcee/emcee_radex.py:120-130,
  * emcee/emcee_radex_2comp.py:122-147): flux_out[N][nJ(src)] in Jy km/s.
@@ -164,7 +215,7 @@ int rx_escprob_batch(rx_handle *h, int method, int N, const double *tau, double 
 /* Kernel timing hook for bench.py: runs rx_lnprob_batch_device `reps` times
  * back-to-back on `stream`, bracketing every launch with HIP events on that
  * same stream, and returns the mean per-launch kernel time in milliseconds.  */
-int rx_time_lnprob_device(rx_handle *h, int N, const double *d_params,
+int rx_time_lnprob_device(rx_handle *h, int N, int ncomp, const double *d_params,
                           const int32_t *d_src_index, double *d_lnp,
                           int32_t *d_status, int32_t *d_niter, void *stream,
                           int reps, double *ms_mean_out);

@@ -23,8 +23,10 @@ EXPORTS = [
     "rx_npart", "rx_partner_ids", "rx_line_data", "rx_set_fortho", "rx_set_iteration_limits",
     "rx_set_source", "rx_lnprob_batch", "rx_lnprob_batch_device", "rx_model_flux_batch",
     "rx_model_flux_batch_device", "rx_solve_batch", "rx_lubksb_batch", "rx_lubksb_pivots_batch", "rx_escprob_batch", "rx_time_lnprob_device",
-    "rx_kernel_name",
+    "rx_kernel_name", "rx_set_issue_order", "rx_stretch_propose_device", "rx_stretch_accept_device",
+    "rx_sampler_run_device",
 ]
+ABI_VERSION = 2
 
 
 class EngineLibraryMissing(ImportError):
@@ -33,7 +35,7 @@ class EngineLibraryMissing(ImportError):
 
 def build(fast: bool = False, force: bool = False) -> str:
     """Compile the HIP extension in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("rx_api.hip", "rx_kernel.hip.inc", "rx_tables.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("rx_api.hip", "rx_kernel.hip.inc", "rx_sampler.hip.inc", "rx_tables.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "radex_emcee_amd.h"))
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
@@ -41,6 +43,17 @@ def build(fast: bool = False, force: bool = False) -> str:
         cmd = ["make", "-C", CSRC, "-B"] + (["FAST=1"] if fast else [])
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
     return LIB_PATH
+
+
+def kernel_source_sha256() -> str:
+    """Hash of everything the device code is compiled from (sources + build flags): profiles record it,
+    and bench.py refuses a PMC summary that was measured on other kernel sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rx_kernel.hip.inc", "rx_sampler.hip.inc", "rx_api.hip", "rx_tables.h", "Makefile"):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
 
 
 _lib = None
@@ -80,13 +93,24 @@ def load():
     L.rx_set_iteration_limits.argtypes = [vp, C.c_int, C.c_int]
     L.rx_set_source.argtypes = [vp, C.c_int, C.c_double, C.c_int, ip, dp, dp, dp, C.c_int, C.c_double]
     L.rx_lnprob_batch.argtypes = [vp, C.c_int, dp, ip, dp, ip, ip]
-    L.rx_lnprob_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.rx_lnprob_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.rx_set_issue_order.argtypes = [vp, C.c_int]
+    u64, i64 = C.c_uint64, C.c_int64
+    L.rx_stretch_propose_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, u64, i64, C.c_int,
+                                            vp, vp, vp, vp, vp, vp, vp]
+    L.rx_stretch_accept_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, u64, i64, C.c_int,
+                                           vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rx_sampler_run_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, u64, i64, C.c_int,
+                                        vp, vp, vp, vp, vp, vp, vp]
     L.rx_model_flux_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, ip]
     L.rx_model_flux_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.rx_solve_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip]
     L.rx_lubksb_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.rx_lubksb_pivots_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip]
     L.rx_escprob_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
-    L.rx_time_lnprob_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
+    L.rx_time_lnprob_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
+    if L.rx_abi_version() != ABI_VERSION:
+        raise EngineLibraryMissing("%s has ABI version %d, this package needs %d: rebuild it"
+                                   % (LIB_PATH, L.rx_abi_version(), ABI_VERSION))
     _lib = L
     return L

@@ -14,6 +14,7 @@
 
 #include "../../include/radex_emcee_amd.h"
 #include "rx_kernel.hip.inc"
+#include "rx_sampler.hip.inc"
 #include "rx_tables.h"
 
 // Padded level counts the solve kernel is instantiated for (one fully unrolled
@@ -199,10 +200,20 @@ struct rx_handle {
     // staging for the host-pointer API + 2-component scratch
     DevBuf<double> s_params, s_lnp, s_flux, s_cflux, s_in3, s_dens, s_xpop, s_tex, s_tau, s_sb;
     DevBuf<int32_t> s_src, s_status, s_niter, s_cstatus, s_cniter, s_srcfix, s_order;
+    // on-device sampler work space (rx_sampler_run_device): proposals, their log-probabilities, ...
+    DevBuf<double> w_q, w_factor, w_lnpq;
+    DevBuf<int32_t> w_widx, w_qsrc, w_qstatus, w_qniter;
     unsigned int *d_order_cnt = nullptr;
+    int issue_order = 1;             // hand large batches out hottest first (rx_set_issue_order; RX_NO_ORDER=1 at rx_create: off)
     int srcfix_value = -1;
     size_t srcfix_filled = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // The queue counter, the fixed-source index, the issue order and the 2-component scratch belong to the
+    // handle, so its launches must not overlap: every launch records ev_done on its stream, and a launch
+    // on ANOTHER stream first makes that stream wait for it (same stream: stream order already does).
+    hipEvent_t ev_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool in_flight = false;
 };
 
 namespace {
@@ -393,9 +404,25 @@ int fixed_src_index(rx_handle *h, RxKArgs &a, hipStream_t st)
     return 0;
 }
 
+// orders `st` behind whatever this handle launched last (no-op on the same stream)
+int order_after_last(rx_handle *h, hipStream_t st)
+{
+    if (h->in_flight && st != h->last_stream) HIPCHK(h, hipStreamWaitEvent(st, h->ev_done, 0));
+    return 0;
+}
+
+int mark_launched(rx_handle *h, hipStream_t st)
+{
+    HIPCHK(h, hipEventRecord(h->ev_done, st));
+    h->last_stream = st;
+    h->in_flight = true;
+    return 0;
+}
+
 int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     if (a.N <= 0) return 0;
+    { int rc = order_after_last(h, st); if (rc) return rc; }
     { int rc = fixed_src_index(h, a, st); if (rc) return rc; }
     const int ncomp = (a.mode == RXK_MODE_SOLVE) ? 1 : a.ncomp;
     const long items = (long)a.N * ncomp;
@@ -410,7 +437,7 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     if (e0) HIPCHK(h, hipEventRecord(e0, st));
     // more items than resident wavefronts: hand the walkers out hottest first (see rx_order_bucket)
     a.order = nullptr;
-    if (items > 2 * cap * RXK_WAVES_PER_BLOCK && !getenv("RX_NO_ORDER")) {
+    if (items > 2 * cap * RXK_WAVES_PER_BLOCK && h->issue_order) {
         HIPCHK(h, h->s_order.reserve((size_t)a.N));
         a.order_out = h->s_order.p;
         a.order_cnt = h->d_order_cnt;
@@ -427,7 +454,7 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     }
     if (e1) HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipGetLastError());
-    return 0;
+    return mark_launched(h, st);
 }
 
 int ensure_comp_scratch(rx_handle *h, RxKArgs &a, int N, int ncomp)
@@ -493,6 +520,8 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipMalloc(&h->d_order_cnt, 2 * RXK_ORDER_BUCKETS * sizeof(unsigned int))) != hipSuccess) return hipfail("hipMalloc", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming)) != hipSuccess) return hipfail("hipEventCreate", e);
+    { const char *no = getenv("RX_NO_ORDER"); h->issue_order = (no && *no && *no != '0') ? 0 : 1; }   // read once
     int nb = 0;
     kernel_fn k = kernel_for(h->NL, 2, h->mol.nlev == h->NL);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
@@ -506,6 +535,8 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
 void rx_destroy(rx_handle *h)
 {
     if (!h) return;
+    if (h->in_flight && h->ev_done) (void)hipEventSynchronize(h->ev_done);   // nothing of this handle still runs
+    h->in_flight = false;
     if (h->d_blob) (void)hipFree(h->d_blob);
     for (double *p : h->d_ksym) (void)hipFree(p);
     if (h->d_srcs) (void)hipFree(h->d_srcs);
@@ -513,10 +544,14 @@ void rx_destroy(rx_handle *h)
     if (h->d_order_cnt) (void)hipFree(h->d_order_cnt);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     h->s_params.release(); h->s_lnp.release(); h->s_flux.release(); h->s_cflux.release();
     h->s_in3.release(); h->s_dens.release(); h->s_xpop.release(); h->s_tex.release();
     h->s_tau.release(); h->s_sb.release(); h->s_src.release(); h->s_status.release();
     h->s_niter.release(); h->s_cstatus.release(); h->s_cniter.release(); h->s_srcfix.release();
+    h->s_order.release();
+    h->w_q.release(); h->w_factor.release(); h->w_lnpq.release(); h->w_widx.release();
+    h->w_qsrc.release(); h->w_qstatus.release(); h->w_qniter.release();
     delete h;
 }
 
@@ -589,18 +624,40 @@ int rx_set_source(rx_handle *h, int src, double tbg, int nJ, const int32_t *Jup,
         S.backi[l] = (hh >= 160.0) ? H_SEED_F : H_THC * pow(x, 3.0) / (exp(hh) - 1.0);
     }
     HIPCHK(h, hipSetDevice(h->device));
+    // the table is read by kernels that may still be running on a non-blocking stream: wait for them
+    if (h->in_flight) { HIPCHK(h, hipEventSynchronize(h->ev_done)); h->in_flight = false; }
     HIPCHK(h, hipMemcpy(h->d_srcs + src, &S, sizeof S, hipMemcpyHostToDevice));
     h->h_srcs[src] = S;
     return 0;
 }
 
-int rx_lnprob_batch_device(rx_handle *h, int N, const double *d_params, const int32_t *d_src_index,
+int rx_set_issue_order(rx_handle *h, int hottest_first)
+{
+    if (!h) return RX_E_ARG;
+    h->issue_order = hottest_first ? 1 : 0;
+    return 0;
+}
+
+// ncomp of a device-pointer batch: the caller states it.  Without a per-walker index the batch addresses
+// slot 0, which must be set and agree; with one the kernel reports every walker whose slot is out of range,
+// unset or of another ncomp as RX_INVALID (the host cannot see a device-side index).
+static int device_batch_ncomp(rx_handle *h, int N, int ncomp, const int32_t *d_src_index)
+{
+    if (ncomp != 1 && ncomp != 2) { h->err = "ncomp must be 1 or 2"; return RX_E_ARG; }
+    if (!d_src_index) {
+        int nc = 0;
+        int rc = source_ncomp(h, nullptr, N, 0, &nc);
+        if (rc) return rc;
+        if (nc != ncomp) { h->err = "ncomp differs from the source in slot 0"; return RX_E_ARG; }
+    }
+    return 0;
+}
+
+int rx_lnprob_batch_device(rx_handle *h, int N, int ncomp, const double *d_params, const int32_t *d_src_index,
                            double *d_lnp, int32_t *d_status, int32_t *d_niter, void *stream)
 {
     if (!h || N < 0 || (N > 0 && (!d_params || !d_lnp))) return RX_E_ARG;
-    // with a device-side index the ncomp of slot 0 defines the batch layout
-    int ncomp = 0;
-    { int rc = source_ncomp(h, nullptr, N, 0, &ncomp); if (rc) return rc; }
+    { int rc = device_batch_ncomp(h, N, ncomp, d_src_index); if (rc) return rc; }
     HIPCHK(h, hipSetDevice(h->device));
     RxKArgs a;
     fill_args(h, a, N, ncomp, RXK_MODE_LNPROB);
@@ -768,13 +825,100 @@ int rx_lubksb_batch(rx_handle *h, int N, int n, const double *A, double *x)
     return rx_lubksb_pivots_batch(h, N, n, A, x, nullptr);
 }
 
-int rx_time_lnprob_device(rx_handle *h, int N, const double *d_params, const int32_t *d_src_index,
+// ---- the stretch move on the device -------------------------------------------------
+static int stretch_args(rx_handle *h, rxs::StretchArgs &A, int nens, int nwalkers, int ndim, double a,
+                        uint64_t seed, int64_t step, int split)
+{
+    if (nens < 1 || nwalkers < 2 || (nwalkers & 1) || ndim < 1 || !(a > 1.0) || step < 0 || step > 0xffffffffLL ||
+        (split != 0 && split != 1) || (long)nens * nwalkers > 0x7fffffffL) { h->err = "stretch move: bad argument"; return RX_E_ARG; }
+    memset(&A, 0, sizeof A);
+    A.nens = nens; A.nwalkers = nwalkers; A.ndim = ndim; A.split = split; A.a = a;
+    A.seed_lo = (uint32_t)seed; A.seed_hi = (uint32_t)(seed >> 32); A.step = (uint32_t)step;
+    return 0;
+}
+
+int rx_stretch_propose_device(rx_handle *h, int nens, int nwalkers, int ndim, double a, uint64_t seed,
+                              int64_t step, int split, const int32_t *d_ens_src, const double *d_coords,
+                              double *d_q, double *d_factor, int32_t *d_widx, int32_t *d_qsrc, void *stream)
+{
+    if (!h || !d_coords || !d_q || !d_factor || !d_widx) return RX_E_ARG;
+    rxs::StretchArgs A;
+    { int rc = stretch_args(h, A, nens, nwalkers, ndim, a, seed, step, split); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    A.ens_src = d_ens_src; A.coords = const_cast<double *>(d_coords);
+    A.q = d_q; A.factor = d_factor; A.widx = d_widx; A.qsrc = d_qsrc;
+    const int n = nens * (nwalkers / 2), tb = 256;
+    hipLaunchKernelGGL(rxs::rx_stretch_propose_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, (hipStream_t)stream, A);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int rx_stretch_accept_device(rx_handle *h, int nens, int nwalkers, int ndim, uint64_t seed, int64_t step,
+                             int split, const double *d_q, const double *d_lnp_q, const double *d_factor,
+                             const int32_t *d_widx, double *d_coords, double *d_lnp, int32_t *d_naccept,
+                             void *stream)
+{
+    if (!h || !d_q || !d_lnp_q || !d_factor || !d_widx || !d_coords || !d_lnp) return RX_E_ARG;
+    rxs::StretchArgs A;
+    { int rc = stretch_args(h, A, nens, nwalkers, ndim, 2.0, seed, step, split); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    A.coords = d_coords; A.lnp = d_lnp; A.naccept = d_naccept;
+    A.q = const_cast<double *>(d_q); A.factor = const_cast<double *>(d_factor);
+    A.lnp_q = d_lnp_q; A.widx = const_cast<int32_t *>(d_widx);
+    const int n = nens * (nwalkers / 2), tb = 256;
+    hipLaunchKernelGGL(rxs::rx_stretch_accept_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, (hipStream_t)stream, A);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int rx_sampler_run_device(rx_handle *h, int nens, int nwalkers, int ncomp, double a, uint64_t seed,
+                          int64_t step0, int nsteps, const int32_t *d_ens_src, double *d_coords,
+                          double *d_lnp, int32_t *d_naccept, double *d_chain, double *d_chain_lnp,
+                          void *stream)
+{
+    if (!h || nsteps < 0 || !d_coords || !d_lnp) return RX_E_ARG;
+    const int ndim = 4 * ncomp;
+    rxs::StretchArgs probe;
+    { int rc = stretch_args(h, probe, nens, nwalkers, ndim, a, seed, step0, 0); if (rc) return rc; }
+    if (step0 + nsteps > 0xffffffffLL) { h->err = "stretch move: step counter exceeds 32 bits"; return RX_E_ARG; }
+    { int rc = device_batch_ncomp(h, nens * nwalkers, ncomp, d_ens_src); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t nq = (size_t)nens * (nwalkers / 2), N = (size_t)nens * nwalkers;
+    HIPCHK(h, h->w_q.reserve(nq * ndim));
+    HIPCHK(h, h->w_factor.reserve(nq));
+    HIPCHK(h, h->w_lnpq.reserve(nq));
+    HIPCHK(h, h->w_widx.reserve(nq));
+    HIPCHK(h, h->w_qsrc.reserve(nq));
+    HIPCHK(h, h->w_qstatus.reserve(nq));
+    HIPCHK(h, h->w_qniter.reserve(nq));
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = order_after_last(h, st); if (rc) return rc; }    // the work space belongs to the handle
+    for (int s = 0; s < nsteps; ++s) {
+        for (int split = 0; split < 2; ++split) {
+            int rc = rx_stretch_propose_device(h, nens, nwalkers, ndim, a, seed, step0 + s, split, d_ens_src, d_coords,
+                                               h->w_q.p, h->w_factor.p, h->w_widx.p, d_ens_src ? h->w_qsrc.p : nullptr, st);
+            if (rc) return rc;
+            rc = rx_lnprob_batch_device(h, (int)nq, ncomp, h->w_q.p, d_ens_src ? h->w_qsrc.p : nullptr, h->w_lnpq.p,
+                                        h->w_qstatus.p, h->w_qniter.p, st);
+            if (rc) return rc;
+            rc = rx_stretch_accept_device(h, nens, nwalkers, ndim, seed, step0 + s, split, h->w_q.p, h->w_lnpq.p,
+                                          h->w_factor.p, h->w_widx.p, d_coords, d_lnp, d_naccept, st);
+            if (rc) return rc;
+        }
+        if (d_chain) HIPCHK(h, hipMemcpyAsync(d_chain + (size_t)s * N * ndim, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (d_chain_lnp) HIPCHK(h, hipMemcpyAsync(d_chain_lnp + (size_t)s * N, d_lnp, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    return nsteps > 0 ? mark_launched(h, st) : 0;
+}
+
+int rx_time_lnprob_device(rx_handle *h, int N, int ncomp, const double *d_params, const int32_t *d_src_index,
                           double *d_lnp, int32_t *d_status, int32_t *d_niter, void *stream,
                           int reps, double *ms_mean_out)
 {
-    if (!h || reps < 1 || !ms_mean_out) return RX_E_ARG;
-    int ncomp = 0;
-    { int rc = source_ncomp(h, nullptr, N, 0, &ncomp); if (rc) return rc; }
+    if (!h || reps < 1 || !ms_mean_out || N < 0 || (N > 0 && (!d_params || !d_lnp))) return RX_E_ARG;
+    *ms_mean_out = 0.0;
+    if (N == 0) return 0;                        // nothing is launched, no event is recorded
+    { int rc = device_batch_ncomp(h, N, ncomp, d_src_index); if (rc) return rc; }
     HIPCHK(h, hipSetDevice(h->device));
     RxKArgs a;
     fill_args(h, a, N, ncomp, RXK_MODE_LNPROB);

@@ -100,13 +100,23 @@ class Engine:
 
     # -- batched evaluation, host buffers --------------------------------------------
     def lnprob_batch(self, params, src_index=None, return_info=False):
-        ncomp = self._sources[0]["ncomp"] if 0 in self._sources else 1
-        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4 * ncomp)
+        si = None if src_index is None else np.ascontiguousarray(src_index, dtype=np.int32).ravel()
+        # the batch layout follows the sources the batch addresses (the library checks they all agree)
+        slot = 0 if si is None or len(si) == 0 else int(si[0])
+        if slot not in self._sources:
+            raise EngineError("source slot %d not set" % slot)
+        ncomp = self._sources[slot]["ncomp"]
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        if params.ndim != 2 or params.shape[1] != 4 * ncomp:
+            if params.size % (4 * ncomp):
+                raise ValueError("params must be [N, %d] for a %d-component source" % (4 * ncomp, ncomp))
+            params = params.reshape(-1, 4 * ncomp)
         N = params.shape[0]
+        if si is not None and len(si) != N:
+            raise ValueError("src_index must have one entry per walker (%d != %d)" % (len(si), N))
         lnp = np.empty(N)
         status = np.empty(N, dtype=np.int32)
         niter = np.empty(N, dtype=np.int32)
-        si = None if src_index is None else np.ascontiguousarray(src_index, dtype=np.int32)
         self._chk(self._L.rx_lnprob_batch(self._h, N, _dp(params), _ip(si), _dp(lnp), _ip(status), _ip(niter)),
                   "rx_lnprob_batch")
         return (lnp, status, niter) if return_info else lnp
@@ -160,11 +170,21 @@ class Engine:
         return out
 
     # -- batched evaluation, device-resident torch tensors -------------------------------
-    def lnprob_batch_torch(self, params, lnp=None, status=None, niter=None, src_index=None, stream=None):
-        """params: CUDA float64 tensor [N, ndim] on this engine's device; asynchronous on `stream`."""
+    def set_issue_order(self, hottest_first=True):
+        """Scheduling of large batches (rx_set_issue_order); results do not depend on it."""
+        self._chk(self._L.rx_set_issue_order(self._h, 1 if hottest_first else 0), "rx_set_issue_order")
+
+    @staticmethod
+    def _stream(dev, stream):
         import torch
-        assert params.is_cuda and params.dtype == torch.float64 and params.is_contiguous()
-        N = params.shape[0]
+        return torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+
+    def lnprob_batch_torch(self, params, lnp=None, status=None, niter=None, src_index=None, stream=None):
+        """params: CUDA float64 tensor [N, 4*ncomp] on this engine's device; asynchronous on `stream`."""
+        import torch
+        assert params.is_cuda and params.dtype == torch.float64 and params.is_contiguous() and params.dim() == 2
+        N, ndim = params.shape
+        assert ndim in (4, 8), "params must be [N, 4] or [N, 8]"
         dev = params.device
         if lnp is None:
             lnp = torch.empty(N, dtype=torch.float64, device=dev)
@@ -172,19 +192,48 @@ class Engine:
             status = torch.empty(N, dtype=torch.int32, device=dev)
         if niter is None:
             niter = torch.empty(N, dtype=torch.int32, device=dev)
-        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        if src_index is not None:
+            assert src_index.is_cuda and src_index.dtype == torch.int32 and src_index.numel() == N
         si = 0 if src_index is None else src_index.data_ptr()
-        self._chk(self._L.rx_lnprob_batch_device(self._h, N, params.data_ptr(), si, lnp.data_ptr(),
-                                                 status.data_ptr(), niter.data_ptr(), st), "rx_lnprob_batch_device")
+        self._chk(self._L.rx_lnprob_batch_device(self._h, N, ndim // 4, params.data_ptr(), si, lnp.data_ptr(),
+                                                 status.data_ptr(), niter.data_ptr(), self._stream(dev, stream)),
+                  "rx_lnprob_batch_device")
         return lnp, status, niter
 
     def time_lnprob_torch(self, params, lnp, status, niter, reps=10, src_index=None, stream=None):
         """Mean per-launch kernel time [ms] from HIP events recorded on the launch stream."""
-        import torch
-        st = torch.cuda.current_stream(params.device).cuda_stream if stream is None else stream
         ms = C.c_double(0.0)
         si = 0 if src_index is None else src_index.data_ptr()
-        self._chk(self._L.rx_time_lnprob_device(self._h, params.shape[0], params.data_ptr(), si, lnp.data_ptr(),
-                                                status.data_ptr(), niter.data_ptr(), st, int(reps),
+        self._chk(self._L.rx_time_lnprob_device(self._h, params.shape[0], params.shape[1] // 4, params.data_ptr(), si,
+                                                lnp.data_ptr(), status.data_ptr(), niter.data_ptr(),
+                                                self._stream(params.device, stream), int(reps),
                                                 C.byref(ms)), "rx_time_lnprob_device")
         return ms.value
+
+    # -- the stretch move on the device (rx_stretch_*_device, rx_sampler_run_device) ---------------
+    def stretch_propose_torch(self, nens, nwalkers, a, seed, step, split, coords, q, factor, widx,
+                              ens_src=None, qsrc=None, stream=None):
+        ndim = coords.shape[-1]
+        self._chk(self._L.rx_stretch_propose_device(
+            self._h, int(nens), int(nwalkers), int(ndim), float(a), int(seed), int(step), int(split),
+            0 if ens_src is None else ens_src.data_ptr(), coords.data_ptr(), q.data_ptr(), factor.data_ptr(),
+            widx.data_ptr(), 0 if qsrc is None else qsrc.data_ptr(), self._stream(coords.device, stream)),
+            "rx_stretch_propose_device")
+
+    def stretch_accept_torch(self, nens, nwalkers, seed, step, split, q, lnp_q, factor, widx, coords, lnp,
+                             naccept=None, stream=None):
+        ndim = coords.shape[-1]
+        self._chk(self._L.rx_stretch_accept_device(
+            self._h, int(nens), int(nwalkers), int(ndim), int(seed), int(step), int(split), q.data_ptr(),
+            lnp_q.data_ptr(), factor.data_ptr(), widx.data_ptr(), coords.data_ptr(), lnp.data_ptr(),
+            0 if naccept is None else naccept.data_ptr(), self._stream(coords.device, stream)),
+            "rx_stretch_accept_device")
+
+    def sampler_run_torch(self, nens, nwalkers, ncomp, a, seed, step0, nsteps, coords, lnp, naccept=None,
+                          chain=None, chain_lnp=None, ens_src=None, stream=None):
+        """nsteps stretch-move steps enqueued on `stream`; everything stays in HBM (asynchronous)."""
+        p = lambda t: 0 if t is None else t.data_ptr()
+        self._chk(self._L.rx_sampler_run_device(
+            self._h, int(nens), int(nwalkers), int(ncomp), float(a), int(seed), int(step0), int(nsteps),
+            p(ens_src), coords.data_ptr(), lnp.data_ptr(), p(naccept), p(chain), p(chain_lnp),
+            self._stream(coords.device, stream)), "rx_sampler_run_device")

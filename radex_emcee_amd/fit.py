@@ -103,7 +103,10 @@ def fit_source(source, data, ncomp=1, nwalkers=None, n_iter_burn=100, n_iter_wal
     rng = np.random.RandomState(seed)
     pos = popt + 1e-3 * rng.randn(nwalkers, ndim)                    # emcee_radex.py:477
     fn = post.lnprob_batch if lnprob_wrapper is None else lnprob_wrapper(post.lnprob_batch)
-    sampler = EnsembleSampler(nwalkers, ndim, fn, vectorize=True, seed=seed)
+    # ONE advancing stream, like the reference's global numpy generator: the sampler continues where the
+    # draw of the starting ball stopped instead of replaying it (same seed twice = the same variates)
+    sampler = EnsembleSampler(nwalkers, ndim, fn, vectorize=True, seed=None)
+    sampler._random = rng
     state = sampler.run_mcmc(pos, n_iter_burn, progress=False)
     sampler.reset()
     sampler.run_mcmc(state, n_iter_walk, progress=False)

@@ -15,6 +15,10 @@ Where the reference evaluates `lnprob` once per walker through `multiprocessing.
 (emcee_radex.py:480-488), this sampler hands each half-ensemble to `log_prob_fn` as ONE
 [N/2, ndim] batch (vectorize=True) -> one kernel launch on the GPU.
 
+`DeviceEnsembleSampler` is the same move with positions, log-probabilities, proposals, accept/reject
+and a counter-based random stream resident on the GPU (csrc/rx_sampler.hip.inc); the host sampler in
+rng="philox" mode replays its stream and is its checker.
+
 Multi-GPU: `ShardedLogProb` splits that batch into contiguous blocks, one per rank
 (one process per GPU), evaluates its block locally and all-gathers the log-probabilities
 (torch.distributed: "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU tests).  Positions and
@@ -24,6 +28,105 @@ and every rank performs the identical accept/reject.
 from __future__ import annotations
 
 import numpy as np
+
+
+# ---- counter-based random stream shared with the device kernels ---------------------------------
+# numpy restatement of radex_emcee_amd/csrc/rx_sampler.hip.inc (Philox4x32-10, the 53-bit uniforms,
+# the keyed permutation of the walkers): the host sampler in rng="philox" mode replays exactly the
+# variates the device kernels draw, which makes it the checker of the on-device stretch move.
+PURPOSE_PROPOSE, PURPOSE_ACCEPT, PURPOSE_PERM = 0, 1, 2
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = 0x9E3779B9, 0xBB67AE85
+_U32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al. 2011) on arrays of 32-bit counters; returns four uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & _U32 for c in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = _M0 * c0, _M1 * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0), p1 & _U32,
+                          (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1), p0 & _U32)
+        k0, k1 = (k0 + _W0) & 0xFFFFFFFF, (k1 + _W1) & 0xFFFFFFFF
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def u53(hi, lo):
+    v = ((hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)) >> np.uint64(11)
+    return v.astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def walker_permutation(n, seed, step, ens):
+    """perm[position] = walker: positions [0, n/2) are the first half of this step's split."""
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    b = 1
+    while (1 << b) < n:
+        b += 1
+    mask = np.uint64((1 << b) - 1)
+    s1, s2 = np.uint64(max(b // 2, 1)), np.uint64(max(b // 3, 1))
+    ka = philox4x32_10(0, ens, step, PURPOSE_PERM, lo, hi)
+    kc = philox4x32_10(1, ens, step, PURPOSE_PERM, lo, hi)
+    mul = [np.uint64(int(ka[i]) | 1) for i in range(3)]
+    add = [np.uint64(int(kc[i])) for i in range(3)]
+
+    def rounds(v):
+        v = (v * mul[0] + add[0]) & mask; v ^= v >> s1
+        v = (v * mul[1] + add[1]) & mask; v ^= v >> s2
+        v = (v * mul[2] + add[2]) & mask; v ^= v >> s1
+        return v
+    v = rounds(np.arange(n, dtype=np.uint64))
+    while True:
+        out = v >= np.uint64(n)
+        if not out.any():
+            break
+        v[out] = rounds(v[out])                          # cycle walking
+    return v.astype(np.int64)
+
+
+def stretch_propose(coords, nens, nwalkers, a, seed, step, split):
+    """numpy mirror of rx_stretch_propose_kernel: returns (q, factor, widx)."""
+    ndim = coords.shape[-1]
+    h = nwalkers // 2
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    X = coords.reshape(nens * nwalkers, ndim)
+    q = np.empty((nens * h, ndim))
+    factor = np.empty(nens * h)
+    widx = np.empty(nens * h, dtype=np.int32)
+    j = np.arange(h)
+    for e in range(nens):
+        perm = walker_permutation(nwalkers, seed, step, e)
+        r = philox4x32_10(j, e, step, PURPOSE_PROPOSE + 16 * split, lo, hi)
+        u, u2 = u53(r[0], r[1]), u53(r[2], r[3])
+        t1 = (a - 1.0) * u + 1.0
+        z = t1 * t1 / a
+        ri = np.minimum((u2 * float(h)).astype(np.int64), h - 1)
+        ws = e * nwalkers + perm[split * h + j]
+        wc = e * nwalkers + perm[(1 - split) * h + ri]
+        sl = slice(e * h, (e + 1) * h)
+        q[sl] = X[wc] - (X[wc] - X[ws]) * z[:, None]
+        factor[sl] = (ndim - 1.0) * np.log(z)
+        widx[sl] = ws
+    return q, factor, widx
+
+
+def stretch_accept(coords, lnp, naccept, q, lnp_q, factor, widx, nens, nwalkers, seed, step, split):
+    """numpy mirror of rx_stretch_accept_kernel (in place)."""
+    h = nwalkers // 2
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    X = coords.reshape(nens * nwalkers, -1)
+    j = np.arange(h)
+    for e in range(nens):
+        r = philox4x32_10(j, e, step, PURPOSE_ACCEPT + 16 * split, lo, hi)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lu = np.log(u53(r[0], r[1]))
+            sl = slice(e * h, (e + 1) * h)
+            w = widx[sl]
+            acc = lu < (factor[sl] + lnp_q[sl]) - lnp[w]
+        X[w[acc]] = q[sl][acc]
+        lnp[w[acc]] = lnp_q[sl][acc]
+        if naccept is not None:
+            naccept[w[acc]] += 1
 
 
 class State:
@@ -38,7 +141,7 @@ class State:
 
 class EnsembleSampler:
     def __init__(self, nwalkers, ndim, log_prob_fn, args=None, kwargs=None, pool=None,
-                 vectorize=False, a=2.0, seed=None):
+                 vectorize=False, a=2.0, seed=None, rng="numpy"):
         if nwalkers < 2 * ndim:
             raise ValueError("The number of walkers needs to be at least twice the dimension "
                              "of your parameter space")
@@ -52,6 +155,13 @@ class EnsembleSampler:
         self.vectorize = bool(vectorize)
         self.a = float(a)
         self._random = np.random.RandomState(seed)
+        # rng="philox": draw the counter-based stream of the device kernels (checker of
+        # DeviceEnsembleSampler) instead of numpy's Mersenne Twister (emcee's own generator)
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self.rng = rng
+        self.seed = 0 if seed is None else int(seed)
+        self.step_counter = 0
         self.reset()
 
     # --- bookkeeping ---------------------------------------------------------------------
@@ -125,7 +235,18 @@ class EnsembleSampler:
         state.random_state = self.random_state
         return state
 
+    def _step_philox(self, state):
+        n, a, seed, step = self.nwalkers, self.a, self.seed, self.step_counter
+        for split in range(2):
+            q, factor, widx = stretch_propose(state.coords, 1, n, a, seed, step, split)
+            new_lp = self.compute_log_prob(q)
+            stretch_accept(state.coords, state.log_prob, self._accepted, q, new_lp, factor, widx, 1, n, seed,
+                           step, split)
+        self.step_counter += 1
+
     def _step(self, state):
+        if self.rng == "philox":
+            return self._step_philox(state)
         n, ndim, a, rng = self.nwalkers, self.ndim, self.a, self._random
         all_inds = np.arange(n)
         inds = all_inds % 2
@@ -157,43 +278,293 @@ class _Wrapper:
         return self.f(x, *self.args, **self.kwargs)
 
 
+def block_partition(N, world, rank):
+    """Contiguous blocks of ceil(N/world) rows: (lo, hi, per).  Every rank but the last non-empty one
+    holds a full block, so the gathered [world*per] vector holds the N results in order."""
+    per = -(-N // world)
+    lo = min(rank * per, N)
+    return lo, min(lo + per, N), per
+
+
 class ShardedLogProb:
     """Evaluate a [N, ndim] batch across the ranks of a torch.distributed group.
 
     Rank r evaluates rows [r*ceil(N/G), ...) with `local_fn` (its own GPU), then ONE
     all_gather of float64 log-probabilities makes the full vector available everywhere
-    (N/(2G) doubles per rank per half-step; latency-bound)."""
+    (N/(2G) doubles per rank per half-step; latency-bound).
 
-    def __init__(self, local_fn, group=None, device=None):
+    tensors=True: tensor in, tensor out -- with a CUDA batch the block, the evaluator's output and
+    the collective (RCCL over xGMI) all stay in HBM on the current stream; `local_fn(P[lo:hi],
+    out[:hi-lo])` writes its block of log-probabilities into `out`.  tensors=False: `local_fn` maps
+    a numpy block to numpy log-probabilities (host evaluators, gloo tests).  A numpy batch is wrapped
+    without a copy and the result returned as numpy."""
+
+    def __init__(self, local_fn, group=None, device=None, tensors=False):
         import torch.distributed as dist
         self.local_fn = local_fn
+        self.tensors = bool(tensors)      # local_fn(block tensor, out tensor) instead of numpy -> numpy
         self.group = group
         self.dist = dist
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device
+        self._buf = {}
 
     def partition(self, N):
-        per = -(-N // self.world)
-        lo = min(self.rank * per, N)
-        return lo, min(lo + per, N), per
+        return block_partition(N, self.world, self.rank)
 
-    def __call__(self, P):
+    def _buffers(self, per, dev):
         import torch
-        P = np.ascontiguousarray(P, dtype=np.float64)
-        N = len(P)
-        lo, hi, per = self.partition(N)
-        local = np.full(per, -np.inf)
-        if hi > lo:
-            local[:hi - lo] = np.asarray(self.local_fn(P[lo:hi]), dtype=np.float64)
-        dev = self.device if self.device is not None else "cpu"
-        mine = torch.from_numpy(local).to(dev)
-        out = torch.empty(per * self.world, dtype=torch.float64, device=dev)
+        key = (per, str(dev))
+        if key not in self._buf:
+            self._buf[key] = (torch.empty(per, dtype=torch.float64, device=dev),
+                              torch.empty(per * self.world, dtype=torch.float64, device=dev))
+        return self._buf[key]
+
+    def gather(self, mine, out):
+        if self.world == 1:
+            out.copy_(mine)
+            return out
         try:
             self.dist.all_gather_into_tensor(out, mine, group=self.group)
         except (RuntimeError, NotImplementedError):      # backend without the flat form
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            parts = list(out.view(self.world, -1).unbind(0))
             self.dist.all_gather(parts, mine, group=self.group)
-            out = torch.cat(parts)
-        # blocks are contiguous and every rank but the last non-empty one is full
-        return out.cpu().numpy()[:N]
+        return out
+
+    def __call__(self, P):
+        import torch
+        as_numpy = not torch.is_tensor(P)
+        if as_numpy:
+            P = torch.from_numpy(np.ascontiguousarray(P, dtype=np.float64))
+            if self.device is not None and str(self.device) != "cpu":
+                P = P.to(self.device)
+        N = P.shape[0]
+        lo, hi, per = self.partition(N)
+        mine, out = self._buffers(per, P.device)
+        mine.fill_(float("-inf"))
+        if hi > lo:
+            if self.tensors:
+                self.local_fn(P[lo:hi], mine[:hi - lo])
+            else:
+                r = self.local_fn(P[lo:hi].cpu().numpy())
+                mine[:hi - lo].copy_(torch.as_tensor(np.asarray(r, dtype=np.float64)))
+        res = self.gather(mine, out)[:N]
+        return res.cpu().numpy() if as_numpy else res
+
+
+# ---- the stretch move with the state resident on the device -----------------------------------------
+class _HostStretchBackend:
+    """numpy restatement of the device kernels on CPU tensors: the checker of the device sampler and
+    the backend of the multi-process (gloo) tests.  `log_prob_fn(q[n, ndim] numpy) -> lnp[n]`."""
+
+    def __init__(self, log_prob_fn):
+        self.log_prob_fn = log_prob_fn
+        self.device = "cpu"
+
+    def propose(self, S, step, split):
+        q, f, w = stretch_propose(S.coords.numpy(), S.nens, S.nwalkers, S.a, S.seed, step, split)
+        S.q.numpy()[:] = q
+        S.factor.numpy()[:] = f
+        S.widx.numpy()[:] = w
+        if S.qsrc is not None:
+            S.qsrc.numpy()[:] = np.repeat(S.ens_src.numpy(), S.nwalkers // 2)
+
+    def evaluate(self, S, q, out, qsrc):
+        out.numpy()[:] = self.log_prob_fn(q.numpy()) if qsrc is None else self.log_prob_fn(q.numpy(), qsrc.numpy())
+
+    def accept(self, S, step, split, lnp_q):
+        stretch_accept(S.coords.numpy(), S.lnp.numpy(), S.naccept.numpy(), S.q.numpy(), lnp_q.numpy(),
+                       S.factor.numpy(), S.widx.numpy(), S.nens, S.nwalkers, S.seed, step, split)
+
+
+class _EngineStretchBackend:
+    """rx_stretch_propose_device / rx_lnprob_batch_device / rx_stretch_accept_device on the current stream."""
+
+    def __init__(self, engine):
+        import torch
+        self.engine = engine
+        self.device = torch.device("cuda", engine.device)
+
+    def propose(self, S, step, split):
+        self.engine.stretch_propose_torch(S.nens, S.nwalkers, S.a, S.seed, step, split, S.coords, S.q, S.factor,
+                                          S.widx, ens_src=S.ens_src, qsrc=S.qsrc)
+
+    def evaluate(self, S, q, out, qsrc):
+        n = q.shape[0]
+        self.engine.lnprob_batch_torch(q, out, S.qstatus[:n], S.qniter[:n], src_index=qsrc)
+
+    def accept(self, S, step, split, lnp_q):
+        self.engine.stretch_accept_torch(S.nens, S.nwalkers, S.seed, step, split, S.q, lnp_q, S.factor, S.widx,
+                                         S.coords, S.lnp, S.naccept)
+
+
+class DeviceEnsembleSampler:
+    """emcee's EnsembleSampler API subset (see the module docstring) with walker positions,
+    log-probabilities, proposals, accept/reject and the random stream on the device: one half-step =
+    propose kernel -> solve kernel over the proposals -> accept kernel, nothing crosses PCIe
+    [/root/reference/emcee/emcee_radex.py:483-499].
+
+    engine    radex_emcee_amd.engine.Engine whose source slot(s) are set (GPU path), or
+    log_prob_fn  a host function (numpy in, numpy out): CPU restatement of the same kernels (checker)
+    nens      independent ensembles advancing together (BASELINE config 3: one per source);
+              ens_src[nens] = source slot of each (default: slot 0 for all)
+    group     torch.distributed group: each half-step's proposals are evaluated in contiguous
+              blocks, one per rank, and ONE all_gather of log-probabilities (RCCL on GPUs) precedes the
+              accept step; positions and the counter-based random stream are replicated, so the
+              proposals need no exchange and every rank accepts identically."""
+
+    def __init__(self, nwalkers, ndim, engine=None, log_prob_fn=None, nens=1, ens_src=None, a=2.0, seed=0,
+                 group=None, sharded=None):
+        import torch
+        if nwalkers < 2 * ndim:
+            raise ValueError("The number of walkers needs to be at least twice the dimension "
+                             "of your parameter space")
+        if nwalkers % 2:
+            raise ValueError("The number of walkers must be even")
+        if (engine is None) == (log_prob_fn is None):
+            raise ValueError("give exactly one of engine / log_prob_fn")
+        self.nwalkers, self.ndim, self.nens = int(nwalkers), int(ndim), int(nens)
+        self.a, self.seed = float(a), int(seed)
+        self.engine = engine
+        self.backend = _EngineStretchBackend(engine) if engine is not None else _HostStretchBackend(log_prob_fn)
+        dev = self.backend.device
+        N, nq = self.nens * self.nwalkers, self.nens * (self.nwalkers // 2)
+        self.N, self.nq = N, nq
+        self.coords = torch.zeros(N, ndim, dtype=torch.float64, device=dev)
+        self.lnp = torch.zeros(N, dtype=torch.float64, device=dev)
+        self.naccept = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.q = torch.empty(nq, ndim, dtype=torch.float64, device=dev)
+        self.factor = torch.empty(nq, dtype=torch.float64, device=dev)
+        self.widx = torch.empty(nq, dtype=torch.int32, device=dev)
+        self.qstatus = torch.empty(nq, dtype=torch.int32, device=dev)
+        self.qniter = torch.empty(nq, dtype=torch.int32, device=dev)
+        self.ens_src = self.qsrc = None
+        if ens_src is not None:
+            self.ens_src = torch.as_tensor(np.asarray(ens_src, dtype=np.int32)).to(dev)
+            if self.ens_src.numel() != self.nens:
+                raise ValueError("ens_src needs one source slot per ensemble")
+            self.qsrc = torch.empty(nq, dtype=torch.int32, device=dev)
+        self.group = group
+        self.world = 1
+        if group is not None or sharded:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+            self._dist = dist
+        lo, hi, per = block_partition(nq, self.world, getattr(self, "rank", 0))
+        self._lo, self._hi, self._per = lo, hi, per
+        self.lnp_q = torch.empty(per * self.world, dtype=torch.float64, device=dev)
+        self._mine = torch.empty(per, dtype=torch.float64, device=dev)
+        self.step_counter = 0
+        self.reset()
+
+    # --- bookkeeping (emcee API) ------------------------------------------------------------------
+    def reset(self):
+        self._chain, self._chain_lnp = [], []
+        self.naccept.zero_()
+        self.iteration = 0
+
+    @property
+    def acceptance_fraction(self):
+        v = self.naccept.cpu().numpy().astype(np.float64) / float(max(self.iteration, 1))
+        return v if self.nens == 1 else v.reshape(self.nens, self.nwalkers)
+
+    def _cat(self, parts, tail):
+        import torch
+        if not parts:
+            return np.empty((0,) + tail)
+        return torch.cat(parts).cpu().numpy()
+
+    def get_chain(self, flat=False, thin=1, discard=0):
+        v = self._cat(self._chain, (self.N, self.ndim))[discard::thin]
+        if self.nens > 1:
+            v = v.reshape(len(v), self.nens, self.nwalkers, self.ndim)
+            return v.transpose(1, 0, 2, 3).reshape(self.nens, -1, self.ndim) if flat else v
+        return v.reshape(-1, self.ndim) if flat else v
+
+    def get_log_prob(self, flat=False, thin=1, discard=0):
+        v = self._cat(self._chain_lnp, (self.N,))[discard::thin]
+        if self.nens > 1:
+            v = v.reshape(len(v), self.nens, self.nwalkers)
+            return v.transpose(1, 0, 2).reshape(self.nens, -1) if flat else v
+        return v.reshape(-1) if flat else v
+
+    # --- evaluation of one batch of proposals (sharded over the group when there is one) --------------
+    def _evaluate(self, q, qsrc):
+        if self.world == 1:
+            out = self.lnp_q[:q.shape[0]]
+            self.backend.evaluate(self, q, out, qsrc)
+            return out
+        lo, hi = self._lo, self._hi
+        self._mine.fill_(float("-inf"))
+        if hi > lo:
+            self.backend.evaluate(self, q[lo:hi], self._mine[:hi - lo], None if qsrc is None else qsrc[lo:hi])
+        try:
+            self._dist.all_gather_into_tensor(self.lnp_q, self._mine, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            self._dist.all_gather(list(self.lnp_q.view(self.world, -1).unbind(0)), self._mine, group=self.group)
+        return self.lnp_q[:q.shape[0]]
+
+    def compute_log_prob(self, coords):
+        """log-probabilities of [N, ndim] positions (ensemble-major), on the device."""
+        import torch
+        X = torch.as_tensor(np.ascontiguousarray(coords, dtype=np.float64).reshape(self.N, self.ndim)).to(self.coords.device)
+        src = None if self.ens_src is None else self.ens_src.repeat_interleave(self.nwalkers).contiguous()
+        out = torch.empty(self.N, dtype=torch.float64, device=X.device)
+        st = torch.empty(self.N, dtype=torch.int32, device=X.device)
+        if self.engine is not None:
+            self.engine.lnprob_batch_torch(X, out, st, torch.empty_like(st), src_index=src)
+        else:
+            self.backend.evaluate(self, X, out, src)
+        return out
+
+    # --- sampling ---------------------------------------------------------------------------------------
+    def run_mcmc(self, initial_state, nsteps, progress=False, store=True):
+        import torch
+        if isinstance(initial_state, State):
+            coords, lp = initial_state.coords, initial_state.log_prob
+        else:
+            coords, lp = np.asarray(initial_state, dtype=np.float64), None
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        if coords.size != self.N * self.ndim:
+            raise ValueError("incompatible input dimensions")
+        if np.any(np.isinf(coords)):
+            raise ValueError("At least one parameter value was infinite")
+        if np.any(np.isnan(coords)):
+            raise ValueError("At least one parameter value was NaN")
+        self.coords.copy_(torch.from_numpy(coords.reshape(self.N, self.ndim)))
+        if lp is None:
+            self.lnp.copy_(self.compute_log_prob(coords))
+        else:
+            self.lnp.copy_(torch.from_numpy(np.ascontiguousarray(lp, dtype=np.float64).reshape(self.N)))
+        if bool(torch.isnan(self.lnp).any()):
+            raise ValueError("The initial log_prob was NaN")
+        nsteps = int(nsteps)
+        chain = chain_lnp = None
+        if store and nsteps > 0:
+            chain = torch.empty(nsteps, self.N, self.ndim, dtype=torch.float64, device=self.coords.device)
+            chain_lnp = torch.empty(nsteps, self.N, dtype=torch.float64, device=self.coords.device)
+        if self.engine is not None and self.world == 1:
+            # one call enqueues every kernel of every step on the current stream
+            self.engine.sampler_run_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed,
+                                          self.step_counter, nsteps, self.coords, self.lnp, self.naccept,
+                                          chain, chain_lnp, ens_src=self.ens_src)
+        else:
+            for s in range(nsteps):
+                step = self.step_counter + s
+                for split in range(2):
+                    self.backend.propose(self, step, split)
+                    lnp_q = self._evaluate(self.q, self.qsrc)
+                    self.backend.accept(self, step, split, lnp_q)
+                if chain is not None:
+                    chain[s].copy_(self.coords)
+                    chain_lnp[s].copy_(self.lnp)
+        self.step_counter += nsteps
+        self.iteration += nsteps
+        if chain is not None:
+            self._chain.append(chain)
+            self._chain_lnp.append(chain_lnp)
+        shape = (self.N, self.ndim) if self.nens == 1 else (self.nens, self.nwalkers, self.ndim)
+        lshape = (self.N,) if self.nens == 1 else (self.nens, self.nwalkers)
+        return State(self.coords.cpu().numpy().reshape(shape), self.lnp.cpu().numpy().reshape(lshape))

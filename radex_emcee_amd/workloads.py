@@ -43,6 +43,21 @@ def draw_prior_1comp(bounds: np.ndarray, n: int, seed: int) -> np.ndarray:
     return out
 
 
+def draw_prior_2comp(bounds: np.ndarray, n: int, seed: int) -> np.ndarray:
+    """Uniform in the 8-dimensional box intersected with the hard constraints of
+    emcee_radex_2comp.py:199-234 (T2 > T1, size1 >= size2, 9 < N_i - n_i < 18)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, 8))
+    k = 0
+    lo, hi = bounds[:, 0], bounds[:, 1]
+    while k < n:
+        p = lo + (hi - lo) * rng.random(8)
+        if p[5] > p[1] and p[3] >= p[7] and 9.0 < p[2] - p[0] < 18.0 and 9.0 < p[6] - p[4] < 18.0:
+            out[k] = p
+            k += 1
+    return out
+
+
 def config2(n_walkers: int = 1024, seed: int = 1234):
     """Synthetic CO SLED J=1..10, 1 component, z=2.5, truth [3.5, 2.0, 17.5, -9.5]."""
     z = 2.5
@@ -51,6 +66,39 @@ def config2(n_walkers: int = 1024, seed: int = 1234):
     return dict(z=z, tbg=T_CMB0 * (1 + z), Jup=np.arange(1, 11, dtype=np.int32), bounds=b,
                 truth=np.array([3.5, 2.0, 17.5, -9.5]), ncomp=1, T_d=None,
                 walkers=draw_prior_1comp(b, n_walkers, seed))
+
+
+def config3(n_walkers: int = 1024, seed: int = 3333, init: str = "prior", filename=None):
+    """BASELINE configs[2]: all 16 sources of data/flux.dat (/root/reference/data/flux.dat:8-23),
+    1 component, `n_walkers` walkers each, advanced together: per source z, Jup/flux/eflux (the finite
+    CO columns), tbg = 2.7315 (1+z) and the prior box of emcee_radex.py:419-442.
+
+    walkers[16][n_walkers][4]: init="prior": uniform in each source's prior box intersected with
+    10 < p2 - p0 < 17.5 (every walker reaches the solver; the stress shape, like config 2);
+    init="ball": the reference's start, p0 + 1e-3 N(0,1) around its p0 = [4.0, 1.4, 17.8, -9.85]
+    clipped into the box (emcee_radex.py:444-451,477).  Source k lives in slot k; src_index[16*n_walkers]
+    is the per-walker slot of the flattened batch."""
+    from . import data_io
+    data = data_io.read_data(filename or data_io.FLUX_1COMP)
+    names = list(data)
+    sources, walkers = [], []
+    for k, name in enumerate(names):
+        z, _lw, Jup, flux, eflux = data_io.get_source(name, data)
+        tbg, b = data_io.source_setup(z, 1)
+        sources.append(dict(name=name, z=z, tbg=tbg, Jup=Jup.astype(np.int32), flux=flux, eflux=eflux,
+                            bounds=b, ncomp=1, T_d=None, slot=k))
+        if init == "prior":
+            walkers.append(draw_prior_1comp(b, n_walkers, seed + k))
+        elif init == "ball":
+            rng = np.random.default_rng(seed + k)
+            p0 = np.clip(np.array([4.0, 1.4, 17.8, -9.85]), b[:, 0], b[:, 1])
+            walkers.append(p0 + 1e-3 * rng.standard_normal((n_walkers, 4)))
+        else:
+            raise ValueError("init must be 'prior' or 'ball'")
+    walkers = np.array(walkers)
+    src_index = np.repeat(np.arange(len(names), dtype=np.int32), n_walkers)
+    return dict(sources=sources, names=names, walkers=walkers, src_index=src_index, ncomp=1,
+                n_walkers=n_walkers)
 
 
 def config4(n_walkers: int = 2048, seed: int = 4321):

@@ -5,15 +5,19 @@ set -u
 OUT=${1:-gpurun_out/prof}
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-large-batch --no-sampler"
+CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-large-batch --no-sampler --no-config3 --no-sharded"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc4 -- $CMD > $OUT/pmc4.log 2>&1
 python3 - <<PY
-import csv, glob, collections, json
-summary = {"command": "rocprofv3 --pmc <set> -- $CMD (one pass per counter set, scripts/prof_pmc.sh)",
+import csv, glob, collections, json, hashlib, sys
+sys.path.insert(0, ".")
+from radex_emcee_amd import _lib
+summary = {"kernel_source_sha256": _lib.kernel_source_sha256(),
+           "library_sha256": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest(),
+           "command": "rocprofv3 --pmc <set> -- $CMD (one pass per counter set, scripts/prof_pmc.sh)",
            "workload": "1024 config-2 walkers per dispatch", "counters": {},
            "notes": "FETCH_SIZE/WRITE_SIZE are in KiB as reported by rocprofv3; SQ_*_CYCLES/SQ_ACTIVE_*/SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md)"}
 for d in ("pmc1","pmc2","pmc3","pmc4"):

@@ -414,15 +414,17 @@ def test_full_size_properties(engines, mol):
     assert np.max(np.abs(an[pick][fin] - rl[fin]) / np.maximum(np.abs(rl[fin]), 1.0)) < 1e-6
 
 
-def test_issue_order_changes_no_result(engines, mol, monkeypatch):
+def test_issue_order_changes_no_result(engines, mol):
     """Batches larger than the resident wavefronts are handed out hottest walkers first
     (rx_order_*_kernel): a scheduling decision -- every output must be bit-identical without it."""
     eng = engines[2]
     cfg = workloads.config2(6000, seed=77)
     src = _truth_source(eng, mol, cfg)
+    eng.set_issue_order(True)
     lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True)
-    monkeypatch.setenv("RX_NO_ORDER", "1")
+    eng.set_issue_order(False)
     lnp0, st0, nit0 = eng.lnprob_batch(cfg["walkers"], return_info=True)
+    eng.set_issue_order(True)
     assert np.array_equal(st, st0) and np.array_equal(nit, nit0)
     assert np.array_equal(lnp, lnp0, equal_nan=True)
     assert (st == 1).sum() > 0

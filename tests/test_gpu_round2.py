@@ -1,0 +1,344 @@
+"""GPU tests added in round 2: BASELINE config 3 in one launch, the issue order with per-walker sources and
+with two components, full-width parity at the stress sizes, the hardened device-pointer boundary, the
+on-device stretch move against its host checker, and the reference's known-answer tests when a real
+LAMDA co.dat is supplied.  Everything goes through the C ABI; the oracle is only the checker.
+
+Tolerances: as tests/test_gpu_parity.py (flux 1e-4 relative + the background floor; status codes
+equal).  Walkers that run into maxiter amplify round-off over their 200 iterations: their
+deviation is reported separately and bounded more loosely than that of converged walkers."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O                      # noqa: E402  (checker only)
+from radex_emcee_amd import workloads               # noqa: E402
+from radex_emcee_amd.engine import Engine           # noqa: E402
+from test_gpu_parity import _flux_ok, _truth_source   # noqa: E402
+
+NTH = max(1, min(32, len(os.sched_getaffinity(0))))
+RX_OK, RX_MAXITER, RX_INVALID, RX_PRIOR = 0, 1, 2, 3
+
+
+@pytest.fixture(scope="module")
+def eng(co_path):
+    return Engine(co_path)
+
+
+@pytest.fixture(scope="module")
+def mol(co_path):
+    return O.Molecule(co_path)
+
+
+def _rel(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1.0)
+
+
+def _report(tag, lnp, ref, st):
+    """max relative lnprob deviation, separately for converged and maxiter walkers"""
+    fin = np.isfinite(ref)
+    ok, mx = fin & (st == RX_OK), fin & (st == RX_MAXITER)
+    dok = _rel(lnp[ok], ref[ok]).max() if ok.any() else 0.0
+    dmx = _rel(lnp[mx], ref[mx]) if mx.any() else np.zeros(1)
+    print("\n[%s] %d walkers: converged %d (max rel dev of lnprob %.2e); maxiter %d (max %.2e, "
+          "99th pct %.2e, above 1e-4: %d)" % (tag, len(ref), ok.sum(), dok, mx.sum(), dmx.max(),
+                                              np.percentile(dmx, 99), int((dmx > 1e-4).sum())))
+    return dok, dmx
+
+
+def _set_config3(eng, cfg):
+    srcs = []
+    for s in cfg["sources"]:
+        eng.set_source(s["tbg"], s["Jup"], s["flux"], s["eflux"], s["bounds"], src=s["slot"])
+        srcs.append(O.Source(s["tbg"], s["Jup"], s["flux"], s["eflux"], s["bounds"]))
+    return srcs
+
+
+def test_config3_sixteen_sources_one_launch(eng, mol):
+    """BASELINE configs[2]: the 16 sources of flux.dat with their own tbg / bounds / line lists, 512
+    proposals each = one launch of 8192 walkers with a per-walker source slot; the batch is larger than
+    twice the resident wavefronts, so the hottest-first issue order is live together with src_index
+    [/root/reference/emcee/emcee_radex.py:389-442, data/flux.dat:8-23]."""
+    cfg = workloads.config3(512)
+    srcs = _set_config3(eng, cfg)
+    P = cfg["walkers"].reshape(-1, 4)
+    idx = cfg["src_index"]
+    assert len(P) == 8192
+    # interleave the sources: neighbouring walkers belong to different sources
+    perm = np.random.default_rng(8).permutation(len(P))
+    eng.set_issue_order(True)
+    lnp, st, nit = eng.lnprob_batch(P[perm], src_index=idx[perm], return_info=True)
+    eng.set_issue_order(False)
+    lnp0, st0, nit0 = eng.lnprob_batch(P[perm], src_index=idx[perm], return_info=True)
+    eng.set_issue_order(True)
+    assert np.array_equal(lnp, lnp0, equal_nan=True) and np.array_equal(st, st0) and np.array_equal(nit, nit0)
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    lnp, st, nit = lnp[inv], st[inv], nit[inv]
+    for k, s in enumerate(cfg["sources"]):
+        sl = slice(512 * k, 512 * (k + 1))
+        rl, rst, rnit = O.lnprob_batch(mol, srcs[k], P[sl], nthreads=NTH)
+        assert np.array_equal(st[sl], rst), s["name"]
+        assert (nit[sl] == rnit).mean() >= 0.995, s["name"]
+        fin = np.isfinite(rl)
+        assert np.array_equal(fin, np.isfinite(lnp[sl]))
+        okm = fin & (rst == RX_OK)
+        assert _rel(lnp[sl][okm], rl[okm]).max() < 1e-6, s["name"]
+        mx = fin & (rst == RX_MAXITER)
+        if mx.any():
+            assert _rel(lnp[sl][mx], rl[mx]).max() < 1e-3, s["name"]
+        # fluxes of this source's walkers (its own line list) against the oracle
+        flux, fst, fnit = eng.model_flux_batch(P[sl], src=s["slot"], return_info=True)
+        rf, rfst, _ = O.model_flux_batch(mol, srcs[k], P[sl], nthreads=NTH)
+        assert flux.shape == (512, len(s["Jup"])) and np.array_equal(fst, rfst)
+        ok, d = _flux_ok(flux, rf, P[sl], s["tbg"], mol)
+        assert ok.all(), (s["name"], np.argwhere(~ok)[:5], d[~ok][:5])
+    assert (st == RX_MAXITER).sum() > 0 and (st == RX_OK).sum() > 7000
+
+
+def test_two_component_issue_order_against_oracle(eng, mol):
+    """with the issue order active (N*ncomp items > twice the resident wavefronts) a
+    2-component walker must receive ITS components' fluxes: with and without the order, and the oracle."""
+    cfg = workloads.config4(4096)
+    W = cfg["walkers"].copy()
+    W[2048:] = workloads.draw_prior_2comp(cfg["bounds"], 2048, 91)     # spread over the box: the order permutes
+    src = _truth_source(eng, mol, cfg)
+    eng.set_issue_order(True)
+    lnp, st, nit = eng.lnprob_batch(W, return_info=True)
+    eng.set_issue_order(False)
+    lnp0, st0, nit0 = eng.lnprob_batch(W, return_info=True)
+    eng.set_issue_order(True)
+    assert np.array_equal(st, st0) and np.array_equal(nit, nit0)
+    assert np.array_equal(lnp, lnp0, equal_nan=True)
+    rl, rst, rnit = O.lnprob_batch(mol, src, W, nthreads=NTH)
+    assert np.array_equal(st, rst)
+    assert (nit == rnit).mean() >= 0.995
+    fin = np.isfinite(rl)
+    assert np.array_equal(fin, np.isfinite(lnp)) and fin.sum() > 2000
+    dok, dmx = _report("2-comp, 4096 walkers, issue order on", lnp, rl, rst)
+    assert dok < 1e-6 and dmx.max() < 1e-3
+    flux = eng.model_flux_batch(W[2040:2300])
+    rf = O.model_flux_batch(mol, src, W[2040:2300], nthreads=NTH)[0]
+    ok, d = _flux_ok(flux, rf, W[2040:2300], cfg["tbg"], mol, ncomp=2)
+    assert ok.all()
+
+
+def test_full_width_parity_config5(eng, mol):
+    """The stress shape at full width: 65536 config-5 walkers against the oracle on every host thread.
+    Status must be identical; converged walkers within the flux-level tolerance (1e-4) on lnprob -- in
+    practice 1e-6; walkers at maxiter are reported, not hidden."""
+    cfg = workloads.config2(65536, seed=5678)
+    src = _truth_source(eng, mol, cfg)
+    lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True)
+    rl, rst, rnit = O.lnprob_batch(mol, src, cfg["walkers"], nthreads=NTH)
+    assert np.array_equal(st, rst)
+    same = (nit == rnit)
+    print("\niteration counts identical: %d of %d" % (same.sum(), len(same)))
+    assert same.mean() >= 0.999
+    fin = np.isfinite(rl)
+    assert np.array_equal(fin, np.isfinite(lnp))
+    dok, dmx = _report("config 5, 65536 walkers", lnp, rl, rst)
+    assert dok < 1e-4
+    assert np.percentile(dmx, 99) < 1e-4 and dmx.max() < 1e-2
+
+
+def test_full_width_parity_config4(eng, mol):
+    """2048 two-component walkers (config 4's ensemble) against the oracle."""
+    cfg = workloads.config4(2048)
+    src = _truth_source(eng, mol, cfg)
+    lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True)
+    rl, rst, rnit = O.lnprob_batch(mol, src, cfg["walkers"], nthreads=NTH)
+    assert np.array_equal(st, rst) and (nit == rnit).mean() >= 0.995
+    fin = np.isfinite(rl)
+    assert np.array_equal(fin, np.isfinite(lnp)) and fin.sum() > 1000
+    dok, dmx = _report("config 4, 2048 two-component walkers", lnp, rl, rst)
+    assert dok < 1e-6 and dmx.max() < 1e-3
+
+
+def test_device_index_is_validated_not_substituted(co_path, mol):
+    """A device-side source index the host cannot see: slots outside the table, never set, or of another
+    ncomp give RX_INVALID / -inf for that walker -- slot 0 is not silently used; ncomp is the caller's."""
+    import torch
+    e = Engine(co_path)
+    cfg = workloads.config2(64)
+    dev = torch.device("cuda:0")
+    P = torch.from_numpy(cfg["walkers"]).to(dev)
+    # slot 0 unset, slot 5 set: ncomp comes from the argument (the tensor's width), not from slot 0
+    src = _truth_source(e, mol, cfg)
+    e.set_source(cfg["tbg"], cfg["Jup"], src.flux, src.eflux, cfg["bounds"], src=5)
+    e2 = Engine(co_path)
+    e2.set_source(cfg["tbg"], cfg["Jup"], src.flux, src.eflux, cfg["bounds"], src=5)
+    c4 = workloads.config4(8)
+    e2.set_source(c4["tbg"], c4["Jup"], np.ones(10), np.ones(10), c4["bounds"], 2, 40.0, src=6)
+    idx = torch.full((64,), 5, dtype=torch.int32, device=dev)
+    idx[3], idx[4], idx[5], idx[6] = 64, -1, 7, 6          # out of range (2x), never set, 2-component source
+    lnp, st, nit = e2.lnprob_batch_torch(P, src_index=idx)
+    torch.cuda.synchronize()
+    ref = e.lnprob_batch(cfg["walkers"])
+    lnp, st = lnp.cpu().numpy(), st.cpu().numpy()
+    bad = np.array([3, 4, 5, 6])
+    assert np.all(st[bad] == RX_INVALID) and np.all(lnp[bad] == -np.inf)
+    good = np.setdiff1d(np.arange(64), bad)
+    assert np.array_equal(lnp[good], ref[good])
+    # without an index the batch addresses slot 0, which e2 never set: an error, not a guess
+    from radex_emcee_amd.engine import EngineError
+    with pytest.raises(EngineError):
+        e2.lnprob_batch_torch(P)
+    with pytest.raises(EngineError):
+        e.lnprob_batch_torch(torch.zeros(4, 8, dtype=torch.float64, device=dev))   # slot 0 is 1-component
+    # engine.lnprob_batch derives the layout from the slots the batch addresses
+    P8 = c4["walkers"]
+    e2.set_source(c4["tbg"], c4["Jup"], np.ones(10), 0.1 * np.ones(10), c4["bounds"], 2, 40.0, src=6)
+    out = e2.lnprob_batch(P8, src_index=np.full(8, 6, dtype=np.int32))
+    assert out.shape == (8,)
+    with pytest.raises(ValueError):
+        e2.lnprob_batch(P8, src_index=np.full(3, 6, dtype=np.int32))
+    assert e.time_lnprob_torch(P[:0], lnp=torch.empty(0, dtype=torch.float64, device=dev),
+                               status=torch.empty(0, dtype=torch.int32, device=dev),
+                               niter=torch.empty(0, dtype=torch.int32, device=dev)) == 0.0
+    e.close(); e2.close()
+
+
+def test_one_handle_on_two_streams_is_ordered(eng, mol):
+    """the handle owns its queue and scratch; launches of ONE handle on two
+    non-blocking streams are ordered by an event instead of racing."""
+    import torch
+    dev = torch.device("cuda:0")
+    cfgA, cfgB = workloads.config2(2048, seed=21), workloads.config4(1500)
+    eng.set_source(cfgB["tbg"], cfgB["Jup"], np.ones(10), 0.1 * np.ones(10), cfgB["bounds"], 2, 40.0, src=1)
+    _truth_source(eng, mol, cfgA)
+    PA = torch.from_numpy(cfgA["walkers"]).to(dev)
+    PB = torch.from_numpy(cfgB["walkers"]).to(dev)
+    iB = torch.ones(1500, dtype=torch.int32, device=dev)
+    refA = [t.clone() for t in eng.lnprob_batch_torch(PA)]
+    refB = [t.clone() for t in eng.lnprob_batch_torch(PB, src_index=iB)]
+    torch.cuda.synchronize()
+    sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    outA = [torch.empty(2048, dtype=t, device=dev) for t in (torch.float64, torch.int32, torch.int32)]
+    outB = [torch.empty(1500, dtype=t, device=dev) for t in (torch.float64, torch.int32, torch.int32)]
+    for _ in range(4):
+        eng.lnprob_batch_torch(PA, *outA, stream=sA.cuda_stream)
+        eng.lnprob_batch_torch(PB, *outB, src_index=iB, stream=sB.cuda_stream)
+    torch.cuda.synchronize()
+    for got, want in zip(outA + outB, refA + refB):
+        assert torch.equal(torch.nan_to_num(got.double(), neginf=-1e308), torch.nan_to_num(want.double(), neginf=-1e308))
+
+
+# ---- the stretch move on the device (f-1) ------------------------------------------------------------
+def test_device_sampler_is_the_host_checker_bit_for_bit(eng, mol):
+    """DeviceEnsembleSampler (propose / solve / accept kernels, state in HBM) against the host sampler
+    replaying the same counter-based stream in numpy and calling rx_lnprob_batch for the proposals:
+    identical chain and log-probabilities, reproducible per seed, different for another seed."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    cfg = workloads.config2(128)
+    _truth_source(eng, mol, cfg)
+    p0 = cfg["truth"] + 1e-2 * np.random.RandomState(5).randn(128, 4)
+    d = DeviceEnsembleSampler(128, 4, engine=eng, seed=42)
+    st = d.run_mcmc(p0, 30)
+    h = EnsembleSampler(128, 4, eng.lnprob_batch, vectorize=True, seed=42, rng="philox")
+    sh = h.run_mcmc(p0, 30)
+    assert np.array_equal(d.get_chain(), h.get_chain())
+    assert np.array_equal(d.get_log_prob(), h.get_log_prob())
+    assert np.array_equal(st.coords, sh.coords) and np.array_equal(st.log_prob, sh.log_prob)
+    assert np.array_equal(d.acceptance_fraction, h.acceptance_fraction)
+    assert 0.1 < d.acceptance_fraction.mean() < 0.9
+    d2 = DeviceEnsembleSampler(128, 4, engine=eng, seed=42)
+    st10 = d2.run_mcmc(p0, 10)
+    d2.run_mcmc(st10, 20)                                   # resuming continues the step counter
+    assert np.array_equal(d2.get_chain(), d.get_chain())
+    d3 = DeviceEnsembleSampler(128, 4, engine=eng, seed=43)
+    d3.run_mcmc(p0, 5)
+    assert not np.array_equal(d3.get_chain(), d.get_chain()[:5])
+
+
+def test_device_sampler_samples_the_posterior(eng, mol):
+    """Statistical validity on the real likelihood: the chain of the device sampler has the moments of
+    the chain the host sampler draws with numpy's generator (emcee's own) -- same target."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    cfg = workloads.config2(64)
+    _truth_source(eng, mol, cfg)
+    p0 = cfg["truth"] + 1e-3 * np.random.RandomState(1).randn(64, 4)
+    d = DeviceEnsembleSampler(64, 4, engine=eng, seed=7)
+    d.run_mcmc(p0, 700)
+    h = EnsembleSampler(64, 4, eng.lnprob_batch, vectorize=True, seed=3)
+    h.run_mcmc(p0, 700)
+    a, b = d.get_chain(flat=True, discard=300), h.get_chain(flat=True, discard=300)
+    # pressure n*T is the well-constrained combination; size and column are degenerate: compare medians
+    # in units of the other chain's spread
+    for f in (lambda c: c[:, 0] + c[:, 1], lambda c: c[:, 2] + c[:, 3], lambda c: c[:, 1]):
+        sa, sb = f(a), f(b)
+        assert abs(np.median(sa) - np.median(sb)) < 0.5 * max(sa.std(), sb.std()) + 0.02
+        assert 0.5 < sa.std() / sb.std() < 2.0
+    assert abs(d.acceptance_fraction.mean() - h.acceptance_fraction.mean()) < 0.1
+
+
+def test_device_sampler_several_sources_and_two_components(eng, mol):
+    """Config 3's shape: ensembles of different sources advance in the same launches and each is the
+    chain it is alone; config 4's shape: 8 parameters."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    cfg = workloads.config3(32, init="ball")
+    _set_config3(eng, cfg)
+    d = DeviceEnsembleSampler(32, 4, engine=eng, nens=16, ens_src=np.arange(16), seed=9)
+    st = d.run_mcmc(cfg["walkers"], 12)
+    ch = d.get_chain()
+    assert ch.shape == (12, 16, 32, 4) and st.coords.shape == (16, 32, 4)
+    for k in (0, 7, 15):
+        def fn(P, k=k):
+            return eng.lnprob_batch(P, src_index=np.full(len(P), k, dtype=np.int32))
+        h = EnsembleSampler(32, 4, fn, vectorize=True, seed=9, rng="philox")
+        # ensemble k of a multi-ensemble run draws the stream of ensemble index k: replay it
+        from radex_emcee_amd import sampler as S
+        coords = cfg["walkers"][k].copy()
+        lnp = fn(coords)
+        for step in range(12):
+            for split in range(2):
+                full = np.zeros((16, 32, 4)); full[k] = coords
+                q, f, w = S.stretch_propose(full, 16, 32, 2.0, 9, step, split)
+                sl = slice(16 * k, 16 * (k + 1))
+                wl = w[sl] - 32 * k
+                nl = fn(q[sl])
+                r = S.philox4x32_10(np.arange(16), k, step, S.PURPOSE_ACCEPT + 16 * split, 9, 0)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    acc = np.log(S.u53(r[0], r[1])) < (f[sl] + nl) - lnp[wl]
+                coords[wl[acc]] = q[sl][acc]
+                lnp[wl[acc]] = nl[acc]
+            assert np.array_equal(ch[step, k], coords), (k, step)
+    # two components
+    c4 = workloads.config4(64)
+    _truth_source(eng, mol, c4)
+    d = DeviceEnsembleSampler(64, 8, engine=eng, seed=2)
+    d.run_mcmc(c4["walkers"], 6)
+    h = EnsembleSampler(64, 8, eng.lnprob_batch, vectorize=True, seed=2, rng="philox")
+    h.run_mcmc(c4["walkers"], 6)
+    assert np.array_equal(d.get_chain(), h.get_chain())
+    _truth_source(eng, mol, workloads.config2(8))
+
+
+def test_reference_kats_with_a_real_co_dat_on_the_gpu():
+    """/root/reference/emcee/pyradex/tests/test_radex.py:99-115 (Tex, tau, populations of CO 1-0) and
+    :175-200 (the chain of Tex values as parameters change) through radex.Radex -> rx_solve_batch.
+    They need the LAMDA co.dat the reference does not ship: activated by RADEX_DATAPATH."""
+    dp = os.getenv("RADEX_DATAPATH")
+    if not dp or not os.path.exists(os.path.join(dp, "co.dat")):
+        pytest.skip("real LAMDA co.dat not available (set RADEX_DATAPATH)")
+    from radex_emcee_amd.radex import Radex
+    rdx = Radex(species='co', collider_densities={'H2': 1e4}, column_per_bin=1e14, deltav=1.0,
+                temperature=30, tbackground=2.73, datapath=dp)
+    rdx.run_radex()
+    np.testing.assert_approx_equal(rdx.tex[0], 56.131, 5)
+    np.testing.assert_approx_equal(rdx.tau[0], 1.786E-03, 4)
+    np.testing.assert_approx_equal(rdx.upperlevelpop[0], 3.640E-01, 4)
+    np.testing.assert_approx_equal(rdx.lowerlevelpop[0], 1.339E-01, 4)
+    RR = Radex(datapath=dp, species='co', column=1e15, density=1e3, temperature=20)
+    RR.run_radex()
+    np.testing.assert_almost_equal(RR.tex[0], 8.69274406690759, decimal=2)
+    RR.column = 1e14
+    RR.run_radex()
+    np.testing.assert_almost_equal(RR.tex[0], 8.0986662583317646, decimal=2)
+    RR.density = 1e4
+    RR.run_radex()
+    np.testing.assert_almost_equal(RR.tex[0], 25.381267019506591, decimal=1)
+    RR.temperature = 25
+    RR.run_radex()
+    np.testing.assert_almost_equal(RR.tex[0], 37.88, decimal=1)
