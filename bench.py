@@ -349,7 +349,7 @@ def main():
             from radex_emcee_amd.sampler import DeviceEnsembleSampler, EnsembleSampler, State
             rs = np.random.RandomState(99)
             p0 = cfg["truth"] + 1e-3 * rs.randn(nw, 4)
-            dsm = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)
+            dsm = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)       # schedule="dataflow"
             sd = dsm.run_mcmc(p0, 20, store=False)                       # a short burn-in
             torch.cuda.synchronize()
             nst = 100
@@ -357,18 +357,38 @@ def main():
             sd = dsm.run_mcmc(State(sd.coords, sd.log_prob), nst, store=False)
             torch.cuda.synchronize()
             tsd = time.perf_counter() - ts
-            # the kernel time of one half-step of THIS chain: its latest proposals, timed alone
-            qo = [torch.empty(nw // 2, dtype=t, device=dev) for t in (torch.float64, torch.int32, torch.int32)]
-            hms = eng.time_lnprob_torch(dsm.q, *qo, reps=10, stream=stream)
+            # the same 100 steps again under the half-step schedule (identical proposals), then once more with
+            # HIP events around every solve launch: the mean kernel time of THIS chain's half-steps (a
+            # half-step lasts as long as its slowest proposal, which varies from one half-step to the next)
+            dsm2 = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7, schedule="halfsteps")
+            s2 = dsm2.run_mcmc(p0, 20, store=False)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            s2b = dsm2.run_mcmc(State(s2.coords, s2.log_prob), nst, store=False)
+            torch.cuda.synchronize()
+            tsh = time.perf_counter() - ts
+            same = bool(np.array_equal(s2b.coords, sd.coords) and np.array_equal(s2b.log_prob, sd.log_prob))
+            dsm3 = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7, schedule="halfsteps")
+            s3 = dsm3.run_mcmc(p0, 20, store=False)
+            dsm3.time_solves = True
+            dsm3.run_mcmc(State(s3.coords, s3.log_prob), nst, store=False)
+            hms = dsm3.last_solve_ms / (2 * nst)
             ideal = nw / (2.0 * hms * 1e-3)
             out["sampler"] = {"walker_steps_per_s": round(nw * nst / tsd, 1), "steps": nst,
                               "ms_per_step": round(tsd / nst * 1e3, 4),
-                              "half_step_kernel_ms": round(hms, 4),
-                              "bound_walkers_over_two_half_step_kernels": round(ideal, 1),
-                              "fraction_of_bound": round(nw * nst / tsd / ideal, 4),
+                              "schedule": "dataflow: ONE persistent kernel, every proposal starts when the two "
+                                          "walkers it reads are final (rx_sampler_run_async_device)",
                               "acceptance": round(float(dsm.acceptance_fraction.mean()), 3),
-                              "note": "DeviceEnsembleSampler: propose / solve / accept kernels, positions, "
-                                      "log-probabilities and the Philox stream resident in HBM; no PCIe per step"}
+                              "half_step_schedule": {
+                                  "walker_steps_per_s": round(nw * nst / tsh, 1), "ms_per_step": round(tsh / nst * 1e3, 4),
+                                  "half_step_kernel_ms": round(hms, 4),
+                                  "bound_walkers_over_two_half_step_kernels": round(ideal, 1),
+                                  "fraction_of_bound": round(nw * nst / tsh / ideal, 4),
+                                  "same_chain_as_dataflow": same,
+                                  "note": "propose / solve / accept launches per half-step (rx_sampler_run_device); a "
+                                          "half-step lasts as long as its slowest proposal"},
+                              "note": "DeviceEnsembleSampler: positions, log-probabilities and the Philox stream "
+                                      "resident in HBM; no PCIe per step"}
             smp = EnsembleSampler(nw, 4, eng.lnprob_batch, vectorize=True, seed=7)
             state = smp.run_mcmc(p0, 5, progress=False)
             ts = time.perf_counter()

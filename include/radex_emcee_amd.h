@@ -104,6 +104,12 @@ int rx_set_source(rx_handle *h, int src, double tbg, int nJ, const int32_t *Jup,
                   const double *flux, const double *eflux, const double *bounds,
                   int ncomp, double T_d);
 
+/* Replaces lnlike(p, Jup, flux, eflux, R) (emcee/emcee_radex.py:132-167,
+ * emcee/emcee_radex_2comp.py:169-196) on its own: with the prior of slot `src` disabled,
+ * rx_lnprob_batch* return the log-likelihood alone (lnprior is neither added nor allowed to
+ * short-circuit); enabled = 1 restores lnprob.  rx_set_source re-enables the prior.          */
+int rx_set_source_prior(rx_handle *h, int src, int enabled);
+
 /* Replaces lnprob(p, Jup, flux, eflux, bounds[, T_d]) called once per walker
  * through pool.map (emcee/emcee_radex.py:177-181,
  * emcee/emcee_radex_2comp.py:237-244) by ONE launch over N walkers.
@@ -153,7 +159,21 @@ int rx_set_issue_order(rx_handle *h, int hottest_first);
  *   d_coords on entry; d_chain [nsteps][nens*nwalkers][ndim] and d_chain_lnp
  *   [nsteps][nens*nwalkers] (each optional) receive the state after every step
  *   (get_chain / get_log_prob); d_ens_src [nens] = source slot per ensemble or NULL = slot 0.
- *   Asynchronous.                                                                          */
+ *   Asynchronous -- unless solve_ms_out is given (benchmarks): then HIP events bracket every
+ *   solve launch on `stream`, the call waits for the last one and returns the summed kernel
+ *   time of the 2*nsteps half-steps in milliseconds.                                        */
+/* rx_sampler_run_async_device: the SAME chain as rx_sampler_run_device, bit for bit, run as ONE
+ * persistent kernel in which every (step, half, ensemble, proposal) is a task that starts as soon as
+ * the two walkers it reads are final (per-walker version counters in HBM) instead of waiting for the
+ * whole previous half-step: a proposal that runs into maxiter delays only the tasks that depend on
+ * its walker.  Asynchronous on `stream`; rx_sampler_wait synchronises the stream and reports
+ * RX_E_HIP if a task gave up waiting (2 s wall clock -- the grid always drains).                */
+int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp, double a,
+                                uint64_t seed, int64_t step0, int nsteps,
+                                const int32_t *d_ens_src, double *d_coords, double *d_lnp,
+                                int32_t *d_naccept, double *d_chain, double *d_chain_lnp,
+                                void *stream);
+int rx_sampler_wait(rx_handle *h, void *stream);
 int rx_stretch_propose_device(rx_handle *h, int nens, int nwalkers, int ndim, double a,
                               uint64_t seed, int64_t step, int split,
                               const int32_t *d_ens_src, const double *d_coords, double *d_q,
@@ -166,7 +186,7 @@ int rx_stretch_accept_device(rx_handle *h, int nens, int nwalkers, int ndim, uin
 int rx_sampler_run_device(rx_handle *h, int nens, int nwalkers, int ncomp, double a,
                           uint64_t seed, int64_t step0, int nsteps, const int32_t *d_ens_src,
                           double *d_coords, double *d_lnp, int32_t *d_naccept, double *d_chain,
-                          double *d_chain_lnp, void *stream);
+                          double *d_chain_lnp, double *solve_ms_out, void *stream);
 
 /* Replaces model_lvg(Jup, p, R) (emcee/emcee_radex.py:120-130,
  * emcee/emcee_radex_2comp.py:122-147): flux_out[N][nJ(src)] in Jy km/s.

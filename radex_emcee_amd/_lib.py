@@ -24,7 +24,7 @@ EXPORTS = [
     "rx_set_source", "rx_lnprob_batch", "rx_lnprob_batch_device", "rx_model_flux_batch",
     "rx_model_flux_batch_device", "rx_solve_batch", "rx_lubksb_batch", "rx_lubksb_pivots_batch", "rx_escprob_batch", "rx_time_lnprob_device",
     "rx_kernel_name", "rx_set_issue_order", "rx_stretch_propose_device", "rx_stretch_accept_device",
-    "rx_sampler_run_device",
+    "rx_sampler_run_device", "rx_set_source_prior", "rx_sampler_run_async_device", "rx_sampler_wait",
 ]
 ABI_VERSION = 2
 
@@ -95,19 +95,23 @@ def load():
     L.rx_lnprob_batch.argtypes = [vp, C.c_int, dp, ip, dp, ip, ip]
     L.rx_lnprob_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.rx_set_issue_order.argtypes = [vp, C.c_int]
+    L.rx_set_source_prior.argtypes = [vp, C.c_int, C.c_int]
     u64, i64 = C.c_uint64, C.c_int64
     L.rx_stretch_propose_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, u64, i64, C.c_int,
                                             vp, vp, vp, vp, vp, vp, vp]
     L.rx_stretch_accept_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, u64, i64, C.c_int,
                                            vp, vp, vp, vp, vp, vp, vp, vp]
     L.rx_sampler_run_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, u64, i64, C.c_int,
-                                        vp, vp, vp, vp, vp, vp, vp]
+                                        vp, vp, vp, vp, vp, vp, dp, vp]
     L.rx_model_flux_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, ip]
     L.rx_model_flux_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.rx_solve_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, ip]
     L.rx_lubksb_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     L.rx_lubksb_pivots_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip]
     L.rx_escprob_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    L.rx_sampler_run_async_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, u64, i64, C.c_int,
+                                              vp, vp, vp, vp, vp, vp, vp]
+    L.rx_sampler_wait.argtypes = [vp, vp]
     L.rx_time_lnprob_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
     if L.rx_abi_version() != ABI_VERSION:
         raise EngineLibraryMissing("%s has ABI version %d, this package needs %d: rebuild it"

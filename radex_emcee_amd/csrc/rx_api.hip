@@ -203,6 +203,11 @@ struct rx_handle {
     // on-device sampler work space (rx_sampler_run_device): proposals, their log-probabilities, ...
     DevBuf<double> w_q, w_factor, w_lnpq;
     DevBuf<int32_t> w_widx, w_qsrc, w_qstatus, w_qniter;
+    // dataflow sampler (rx_sampler_run_async_device): per-walker version counters, abort flag
+    DevBuf<uint32_t> w_version;      // [N] version counters, then [RING] per-step counters
+    DevBuf<double> w_hist;           // [RING][N][ndim] positions by version
+    uint32_t *d_abort = nullptr;
+    uint32_t *h_abort = nullptr;     // pinned mirror, filled by an async copy behind every async run
     unsigned int *d_order_cnt = nullptr;
     int issue_order = 1;             // hand large batches out hottest first (rx_set_issue_order; RX_NO_ORDER=1 at rx_create: off)
     int srcfix_value = -1;
@@ -236,6 +241,23 @@ lukernel_fn lukernel_for(int NL)
 #undef RX_CASE
     }
     return nullptr;
+}
+
+typedef void (*sampler_kernel_fn)(const rxs::AsyncArgs);
+sampler_kernel_fn sampler_kernel_for(int NL, int occ, bool exact)
+{
+#ifdef RX_NO_SAMPLER_KERNEL
+    return nullptr;
+#else
+    if (NL == 41 && exact)
+        return occ >= 2 ? rxs::rx_sampler_kernel<41, 2, true> : rxs::rx_sampler_kernel<41, 1, true>;
+    switch (NL) {
+#define RX_CASE(n) case n: return occ >= 2 ? rxs::rx_sampler_kernel<n, 2, false> : rxs::rx_sampler_kernel<n, 1, false>;
+        RX_NL_CASES
+#undef RX_CASE
+    }
+    return nullptr;
+#endif
 }
 
 // exact = the molecule fills the instantiation (nlev == NL): only built for CO's 41 levels
@@ -551,7 +573,9 @@ void rx_destroy(rx_handle *h)
     h->s_niter.release(); h->s_cstatus.release(); h->s_cniter.release(); h->s_srcfix.release();
     h->s_order.release();
     h->w_q.release(); h->w_factor.release(); h->w_lnpq.release(); h->w_widx.release();
-    h->w_qsrc.release(); h->w_qstatus.release(); h->w_qniter.release();
+    h->w_qsrc.release(); h->w_qstatus.release(); h->w_qniter.release(); h->w_version.release(); h->w_hist.release();
+    if (h->d_abort) (void)hipFree(h->d_abort);
+    if (h->h_abort) (void)hipHostFree(h->h_abort);
     delete h;
 }
 
@@ -631,6 +655,17 @@ int rx_set_source(rx_handle *h, int src, double tbg, int nJ, const int32_t *Jup,
     return 0;
 }
 
+int rx_set_source_prior(rx_handle *h, int src, int enabled)
+{
+    if (!h) return RX_E_ARG;
+    if (src < 0 || src >= RX_MAX_SOURCES || !h->h_srcs[src].set) { h->err = "source slot not set"; return RX_E_STATE; }
+    h->h_srcs[src].no_prior = enabled ? 0 : 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->in_flight) { HIPCHK(h, hipEventSynchronize(h->ev_done)); h->in_flight = false; }
+    HIPCHK(h, hipMemcpy(h->d_srcs + src, &h->h_srcs[src], sizeof(RxSourceDev), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int rx_set_issue_order(rx_handle *h, int hottest_first)
 {
     if (!h) return RX_E_ARG;
@@ -653,8 +688,9 @@ static int device_batch_ncomp(rx_handle *h, int N, int ncomp, const int32_t *d_s
     return 0;
 }
 
-int rx_lnprob_batch_device(rx_handle *h, int N, int ncomp, const double *d_params, const int32_t *d_src_index,
-                           double *d_lnp, int32_t *d_status, int32_t *d_niter, void *stream)
+static int lnprob_device(rx_handle *h, int N, int ncomp, const double *d_params, const int32_t *d_src_index,
+                         double *d_lnp, int32_t *d_status, int32_t *d_niter, hipStream_t st,
+                         hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr)
 {
     if (!h || N < 0 || (N > 0 && (!d_params || !d_lnp))) return RX_E_ARG;
     { int rc = device_batch_ncomp(h, N, ncomp, d_src_index); if (rc) return rc; }
@@ -664,7 +700,13 @@ int rx_lnprob_batch_device(rx_handle *h, int N, int ncomp, const double *d_param
     a.params = d_params; a.src_index = d_src_index; a.src_fixed = 0;
     a.lnp = d_lnp; a.status = d_status; a.niter = d_niter;
     { int rc = ensure_comp_scratch(h, a, N, ncomp); if (rc) return rc; }
-    return launch(h, a, (hipStream_t)stream);
+    return launch(h, a, st, e0, e1);
+}
+
+int rx_lnprob_batch_device(rx_handle *h, int N, int ncomp, const double *d_params, const int32_t *d_src_index,
+                           double *d_lnp, int32_t *d_status, int32_t *d_niter, void *stream)
+{
+    return lnprob_device(h, N, ncomp, d_params, d_src_index, d_lnp, d_status, d_niter, (hipStream_t)stream);
 }
 
 int rx_lnprob_batch(rx_handle *h, int N, const double *params, const int32_t *src_index,
@@ -874,7 +916,7 @@ int rx_stretch_accept_device(rx_handle *h, int nens, int nwalkers, int ndim, uin
 int rx_sampler_run_device(rx_handle *h, int nens, int nwalkers, int ncomp, double a, uint64_t seed,
                           int64_t step0, int nsteps, const int32_t *d_ens_src, double *d_coords,
                           double *d_lnp, int32_t *d_naccept, double *d_chain, double *d_chain_lnp,
-                          void *stream)
+                          double *solve_ms_out, void *stream)
 {
     if (!h || nsteps < 0 || !d_coords || !d_lnp) return RX_E_ARG;
     const int ndim = 4 * ncomp;
@@ -893,14 +935,24 @@ int rx_sampler_run_device(rx_handle *h, int nens, int nwalkers, int ncomp, doubl
     HIPCHK(h, h->w_qniter.reserve(nq));
     hipStream_t st = (hipStream_t)stream;
     { int rc = order_after_last(h, st); if (rc) return rc; }    // the work space belongs to the handle
+    // optional: HIP events around every solve launch (one pair per half-step), summed after the last one
+    std::vector<hipEvent_t> ev;
+    if (solve_ms_out) {
+        *solve_ms_out = 0.0;
+        ev.resize((size_t)4 * nsteps, nullptr);
+        for (auto &e : ev) HIPCHK(h, hipEventCreate(&e));
+    }
+    auto drop_events = [&]() { for (auto e : ev) if (e) (void)hipEventDestroy(e); };
     for (int s = 0; s < nsteps; ++s) {
         for (int split = 0; split < 2; ++split) {
             int rc = rx_stretch_propose_device(h, nens, nwalkers, ndim, a, seed, step0 + s, split, d_ens_src, d_coords,
                                                h->w_q.p, h->w_factor.p, h->w_widx.p, d_ens_src ? h->w_qsrc.p : nullptr, st);
             if (rc) return rc;
-            rc = rx_lnprob_batch_device(h, (int)nq, ncomp, h->w_q.p, d_ens_src ? h->w_qsrc.p : nullptr, h->w_lnpq.p,
-                                        h->w_qstatus.p, h->w_qniter.p, st);
-            if (rc) return rc;
+            const size_t ei = (size_t)4 * s + 2 * split;
+            rc = lnprob_device(h, (int)nq, ncomp, h->w_q.p, d_ens_src ? h->w_qsrc.p : nullptr, h->w_lnpq.p,
+                               h->w_qstatus.p, h->w_qniter.p, st, solve_ms_out ? ev[ei] : nullptr,
+                               solve_ms_out ? ev[ei + 1] : nullptr);
+            if (rc) { drop_events(); return rc; }
             rc = rx_stretch_accept_device(h, nens, nwalkers, ndim, seed, step0 + s, split, h->w_q.p, h->w_lnpq.p,
                                           h->w_factor.p, h->w_widx.p, d_coords, d_lnp, d_naccept, st);
             if (rc) return rc;
@@ -908,7 +960,82 @@ int rx_sampler_run_device(rx_handle *h, int nens, int nwalkers, int ncomp, doubl
         if (d_chain) HIPCHK(h, hipMemcpyAsync(d_chain + (size_t)s * N * ndim, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));
         if (d_chain_lnp) HIPCHK(h, hipMemcpyAsync(d_chain_lnp + (size_t)s * N, d_lnp, N * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
+    if (solve_ms_out && nsteps > 0) {
+        hipError_t e = hipStreamSynchronize(st);
+        double sum = 0.0;
+        for (size_t i = 0; e == hipSuccess && i + 1 < ev.size(); i += 2) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            sum += ms;
+        }
+        drop_events();
+        if (e != hipSuccess) return hip_fail(h, e, "rx_sampler_run_device: event timing");
+        *solve_ms_out = sum;
+    }
     return nsteps > 0 ? mark_launched(h, st) : 0;
+}
+
+int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp, double a, uint64_t seed,
+                                int64_t step0, int nsteps, const int32_t *d_ens_src, double *d_coords,
+                                double *d_lnp, int32_t *d_naccept, double *d_chain, double *d_chain_lnp,
+                                void *stream)
+{
+    if (!h || nsteps < 0 || !d_coords || !d_lnp) return RX_E_ARG;
+    const int ndim = 4 * ncomp;
+    rxs::AsyncArgs A;
+    memset(&A, 0, sizeof A);
+    { int rc = stretch_args(h, A.s, nens, nwalkers, ndim, a, seed, step0, 0); if (rc) return rc; }
+    if (step0 + nsteps > 0xffffffffLL) { h->err = "stretch move: step counter exceeds 32 bits"; return RX_E_ARG; }
+    { int rc = device_batch_ncomp(h, nens * nwalkers, ncomp, d_ens_src); if (rc) return rc; }
+    const size_t N = (size_t)nens * nwalkers, nq = N / 2;
+    if ((double)nsteps * 2.0 * (double)nq >= 4294967295.0) { h->err = "stretch move: more than 2^32 tasks in one launch"; return RX_E_ARG; }
+    if (nsteps == 0) return 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = order_after_last(h, st); if (rc) return rc; }
+    constexpr int RING = 12;                         // versions of the positions kept readable (see the kernel)
+    HIPCHK(h, h->w_version.reserve(N + RING));
+    HIPCHK(h, h->w_hist.reserve((size_t)RING * N * ndim));
+    if (!h->d_abort) HIPCHK(h, hipMalloc(&h->d_abort, sizeof(uint32_t)));
+    if (!h->h_abort) { HIPCHK(h, hipHostMalloc(&h->h_abort, sizeof(uint32_t))); *h->h_abort = 0; }
+    // few tasks per half-step: one wavefront per SIMD (lowest latency per task), the whole chip so that
+    // wavefronts can run ahead of a slow task; many: two per SIMD (throughput)
+    const int occ = (nq > (size_t)2 * h->num_cu * RXK_WAVES_PER_BLOCK && h->blocks_per_cu2 >= 2) ? 2 : 1;
+    long blocks = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
+    const long need = (long)((2 * nq * (size_t)nsteps + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK);
+    if (blocks > need) blocks = need;
+    sampler_kernel_fn k = sampler_kernel_for(h->NL, occ, h->mol.nlev == h->NL);
+    if (!k) { h->err = "this build has no dataflow sampler kernel"; return RX_E_UNSUPP; }
+    fill_args(h, A.k, (int)N, ncomp, RXK_MODE_LNPROB);
+    A.s.ens_src = d_ens_src; A.s.coords = d_coords; A.s.lnp = d_lnp; A.s.naccept = d_naccept;
+    A.nsteps = nsteps; A.ncomp = ncomp;
+    A.version = h->w_version.p; A.abort_flag = h->d_abort;
+    A.hist = h->w_hist.p; A.done = h->w_version.p + N; A.ring = RING;
+    A.chain = d_chain; A.chain_lnp = d_chain_lnp;
+    A.timeout_ticks = 200000000LL;                   // 2 s of the 100 MHz wall clock: far beyond any real wait
+    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
+    HIPCHK(h, hipMemsetAsync(h->d_abort, 0, sizeof(uint32_t), st));
+    HIPCHK(h, hipMemsetAsync(h->w_version.p, 0, (N + RING) * sizeof(uint32_t), st));
+    HIPCHK(h, hipMemcpyAsync(h->w_hist.p, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));   // version 0
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, A);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(d_coords, h->w_hist.p + (size_t)(nsteps % RING) * N * ndim, N * ndim * sizeof(double),
+                             hipMemcpyDeviceToDevice, st));                                                  // version nsteps
+    HIPCHK(h, hipMemcpyAsync(h->h_abort, h->d_abort, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    return mark_launched(h, st);
+}
+
+int rx_sampler_wait(rx_handle *h, void *stream)
+{
+    if (!h) return RX_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    if (h->h_abort && *h->h_abort) {
+        *h->h_abort = 0;
+        h->err = "dataflow sampler: a task waited longer than the timeout for its inputs (chain incomplete)";
+        return RX_E_HIP;
+    }
+    return 0;
 }
 
 int rx_time_lnprob_device(rx_handle *h, int N, int ncomp, const double *d_params, const int32_t *d_src_index,

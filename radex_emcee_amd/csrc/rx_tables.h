@@ -61,6 +61,7 @@ struct RxMolDev {
 struct RxSourceDev {
     double tbg, T_d, logterm2;
     int32_t nJ, ncomp, data_ok, set;
+    int32_t no_prior, pad_;         // no_prior: lnprob = lnlike alone (rx_set_source_prior)
     int32_t jidx[RXK_MAXNJ];        // Jup-1
     double flux[RXK_MAXNJ];
     double esig[RXK_MAXNJ];         // max(|eflux|, 1e-12)

@@ -98,6 +98,10 @@ class Engine:
         self._chk(rc, "rx_set_source")
         self._sources[int(src)] = dict(nJ=len(Jup), ncomp=int(ncomp))
 
+    def set_source_prior(self, src=0, enabled=True):
+        """enabled=False: lnprob_batch returns the log-likelihood alone for this slot (rx_set_source_prior)."""
+        self._chk(self._L.rx_set_source_prior(self._h, int(src), 1 if enabled else 0), "rx_set_source_prior")
+
     # -- batched evaluation, host buffers --------------------------------------------
     def lnprob_batch(self, params, src_index=None, return_info=False):
         si = None if src_index is None else np.ascontiguousarray(src_index, dtype=np.int32).ravel()
@@ -230,10 +234,28 @@ class Engine:
             "rx_stretch_accept_device")
 
     def sampler_run_torch(self, nens, nwalkers, ncomp, a, seed, step0, nsteps, coords, lnp, naccept=None,
-                          chain=None, chain_lnp=None, ens_src=None, stream=None):
-        """nsteps stretch-move steps enqueued on `stream`; everything stays in HBM (asynchronous)."""
+                          chain=None, chain_lnp=None, ens_src=None, stream=None, time_solves=False):
+        """nsteps stretch-move steps enqueued on `stream`; everything stays in HBM (asynchronous).
+        time_solves: wait for the steps and return the summed solve-kernel time [ms] (HIP events)."""
         p = lambda t: 0 if t is None else t.data_ptr()
+        ms = C.c_double(0.0)
         self._chk(self._L.rx_sampler_run_device(
             self._h, int(nens), int(nwalkers), int(ncomp), float(a), int(seed), int(step0), int(nsteps),
             p(ens_src), coords.data_ptr(), lnp.data_ptr(), p(naccept), p(chain), p(chain_lnp),
+            C.byref(ms) if time_solves else None,
             self._stream(coords.device, stream)), "rx_sampler_run_device")
+        return ms.value if time_solves else None
+
+    def sampler_run_async_torch(self, nens, nwalkers, ncomp, a, seed, step0, nsteps, coords, lnp, naccept=None,
+                                chain=None, chain_lnp=None, ens_src=None, stream=None):
+        """The same chain as sampler_run_torch as ONE persistent dataflow kernel (rx_sampler_run_async_device)."""
+        p = lambda t: 0 if t is None else t.data_ptr()
+        self._chk(self._L.rx_sampler_run_async_device(
+            self._h, int(nens), int(nwalkers), int(ncomp), float(a), int(seed), int(step0), int(nsteps),
+            p(ens_src), coords.data_ptr(), lnp.data_ptr(), p(naccept), p(chain), p(chain_lnp),
+            self._stream(coords.device, stream)), "rx_sampler_run_async_device")
+
+    def sampler_wait(self, device=None, stream=None):
+        import torch
+        dev = torch.device("cuda", self.device) if device is None else device
+        self._chk(self._L.rx_sampler_wait(self._h, self._stream(dev, stream)), "rx_sampler_wait")

@@ -79,9 +79,11 @@ def load_result(path):
 
 
 def fit_source(source, data, ncomp=1, nwalkers=None, n_iter_burn=100, n_iter_walk=None, seed=None,
-               engine=None, warm=True, lnprob_wrapper=None):
+               engine=None, warm=True, lnprob_wrapper=None, sampler="host"):
     """One source end to end.  Defaults are the reference's: 100 walkers x (100 + 500) steps for
-    one component, 400 x (100 + 1000) for two (emcee_radex.py:472-474, 2comp:548-550)."""
+    one component, 400 x (100 + 1000) for two (emcee_radex.py:472-474, 2comp:548-550).
+    sampler="device": the chain runs in HBM (DeviceEnsembleSampler: propose / solve / accept kernels,
+    counter-based random stream); "host": numpy stretch move + one rx_lnprob_batch per half-step."""
     if ncomp == 1:
         z, _lw, Jup, flux, eflux = data_io.get_source(source, data)
         T_d, p0 = None, P0_1COMP
@@ -102,6 +104,18 @@ def fit_source(source, data, ncomp=1, nwalkers=None, n_iter_burn=100, n_iter_wal
     ndim = len(popt)
     rng = np.random.RandomState(seed)
     pos = popt + 1e-3 * rng.randn(nwalkers, ndim)                    # emcee_radex.py:477
+    if sampler == "device":
+        from .sampler import DeviceEnsembleSampler
+        dsm = DeviceEnsembleSampler(nwalkers, ndim, engine=post.engine, seed=0 if seed is None else int(seed),
+                                    ens_src=[post.src] if post.src else None)
+        state = dsm.run_mcmc(pos, n_iter_burn, store=False)
+        dsm.reset()
+        dsm.run_mcmc(state, n_iter_walk)
+        chain, lnprobability, flat = dsm.get_chain(), dsm.get_log_prob(), dsm.get_chain(flat=True)
+        theta_med = np.percentile(flat, 50, axis=0)
+        tup = result_tuple(source, z, bounds, Jup, flux, eflux, popt, pcov, pmin, theta_med, chain,
+                           lnprobability, T_d=T_d)
+        return tup, summarize(flat, ncomp), dsm
     fn = post.lnprob_batch if lnprob_wrapper is None else lnprob_wrapper(post.lnprob_batch)
     # ONE advancing stream, like the reference's global numpy generator: the sampler continues where the
     # draw of the starting ball stopped instead of replaying it (same seed twice = the same variates)

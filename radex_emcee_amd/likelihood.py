@@ -113,29 +113,24 @@ def lnprior(p, bounds, T_d=None, R=None):
 
 
 def lnlike(p, Jup, flux, eflux, R=None, sigma_floor=1e-12):
-    """emcee_radex.py:132-167: Gaussian log-likelihood with the reference's guards."""
+    """emcee_radex.py:132-167 / emcee_radex_2comp.py:169-196: Gaussian log-likelihood with the
+    reference's guards (ValueError of the setters, non-finite data / model / residuals -> -inf,
+    |eflux| floored).  Evaluated by the engine's fused likelihood epilogue with the prior switched off
+    (rx_set_source_prior): the same code path the sampler uses, no second implementation on the host."""
     R = R or globals()["R"]
     p = np.asarray(p, dtype=np.float64)
-    # the model comes from the GPU; chi^2 is formed on the host exactly as the reference does
+    ncomp = p.size // 4
+    Jup = np.asarray(np.int_(Jup))
+    e = np.asarray(eflux, dtype=np.float64)
+    if sigma_floor > 1e-12:                       # (the engine's own floor is the reference's default 1e-12)
+        e = np.maximum(np.abs(e), sigma_floor)
+    wide = np.tile(np.array([-np.inf, np.inf]), (4 * ncomp, 1))
+    R.set_source(R._tbg, Jup, np.asarray(flux, dtype=np.float64), e, wide, ncomp, None, src=0)
+    R.set_source_prior(0, False)
     try:
-        model_flux = model_lvg(Jup, p, R)
-    except ValueError:
-        return -np.inf
-    flux = np.asarray(flux, dtype=np.float64)
-    model_flux = np.asarray(model_flux, dtype=np.float64)
-    eflux = np.asarray(eflux, dtype=np.float64)
-    if not (np.all(np.isfinite(flux)) and np.all(np.isfinite(model_flux))):
-        return -np.inf
-    e = np.maximum(np.abs(eflux), sigma_floor)
-    if not np.all(np.isfinite(e)):
-        return -np.inf
-    with np.errstate(over='ignore', divide='ignore', invalid='ignore'):
-        r = (flux - model_flux) / e
-    if not np.all(np.isfinite(r)):
-        return -np.inf
-    if np.any(np.abs(r) > np.sqrt(np.finfo(np.float64).max) / 10.0):
-        return -np.inf
-    return -0.5 * (np.dot(r, r) + 2.0 * np.sum(np.log(e)))
+        return float(R.lnprob_batch(p[None, :])[0])
+    finally:
+        R.set_source_prior(0, True)
 
 
 def lnprob(p, Jup, flux, eflux, bounds=None, T_d=None):

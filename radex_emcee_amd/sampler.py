@@ -409,13 +409,15 @@ class DeviceEnsembleSampler:
     log_prob_fn  a host function (numpy in, numpy out): CPU restatement of the same kernels (checker)
     nens      independent ensembles advancing together (BASELINE config 3: one per source);
               ens_src[nens] = source slot of each (default: slot 0 for all)
+    schedule  "dataflow" (default, one GPU): the chain as one persistent kernel whose tasks start when
+              their two input walkers are final; "halfsteps": one propose / solve / accept round per half-step
     group     torch.distributed group: each half-step's proposals are evaluated in contiguous
               blocks, one per rank, and ONE all_gather of log-probabilities (RCCL on GPUs) precedes the
               accept step; positions and the counter-based random stream are replicated, so the
               proposals need no exchange and every rank accepts identically."""
 
     def __init__(self, nwalkers, ndim, engine=None, log_prob_fn=None, nens=1, ens_src=None, a=2.0, seed=0,
-                 group=None, sharded=None):
+                 group=None, sharded=None, schedule="dataflow"):
         import torch
         if nwalkers < 2 * ndim:
             raise ValueError("The number of walkers needs to be at least twice the dimension "
@@ -456,7 +458,15 @@ class DeviceEnsembleSampler:
         self._lo, self._hi, self._per = lo, hi, per
         self.lnp_q = torch.empty(per * self.world, dtype=torch.float64, device=dev)
         self._mine = torch.empty(per, dtype=torch.float64, device=dev)
+        # schedule (single GPU, engine backend): "dataflow" = one persistent kernel, every proposal starts
+        # as soon as the two walkers it reads are final (rx_sampler_run_async_device); "halfsteps" = propose /
+        # solve / accept launches per half-step (rx_sampler_run_device).  The chains are bit-identical.
+        if schedule not in ("dataflow", "halfsteps"):
+            raise ValueError("schedule must be 'dataflow' or 'halfsteps'")
+        self.schedule = schedule
         self.step_counter = 0
+        self.time_solves = False          # benchmarks: sum the solve-kernel time of every half-step (HIP events)
+        self.last_solve_ms = None
         self.reset()
 
     # --- bookkeeping (emcee API) ------------------------------------------------------------------
@@ -545,11 +555,17 @@ class DeviceEnsembleSampler:
         if store and nsteps > 0:
             chain = torch.empty(nsteps, self.N, self.ndim, dtype=torch.float64, device=self.coords.device)
             chain_lnp = torch.empty(nsteps, self.N, dtype=torch.float64, device=self.coords.device)
-        if self.engine is not None and self.world == 1:
+        if self.engine is not None and self.world == 1 and self.schedule == "dataflow" and not self.time_solves:
+            self.engine.sampler_run_async_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed,
+                                                self.step_counter, nsteps, self.coords, self.lnp, self.naccept,
+                                                chain, chain_lnp, ens_src=self.ens_src)
+            self.engine.sampler_wait(self.coords.device)
+        elif self.engine is not None and self.world == 1:
             # one call enqueues every kernel of every step on the current stream
-            self.engine.sampler_run_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed,
-                                          self.step_counter, nsteps, self.coords, self.lnp, self.naccept,
-                                          chain, chain_lnp, ens_src=self.ens_src)
+            self.last_solve_ms = self.engine.sampler_run_torch(
+                self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed, self.step_counter, nsteps,
+                self.coords, self.lnp, self.naccept, chain, chain_lnp, ens_src=self.ens_src,
+                time_solves=self.time_solves)
         else:
             for s in range(nsteps):
                 step = self.step_counter + s

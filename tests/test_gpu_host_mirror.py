@@ -110,6 +110,11 @@ def test_fit_source_end_to_end(tmp_path):
     assert post.lnprob(pmin) >= post.lnprob(np.clip(fit.P0_1COMP, b[:, 0], b[:, 1])) - 1e-9   # minimize improved on p0
     fit.save_result(tmp_path / "SDP81_bounds.pickle", tup)
     assert fit.load_result(tmp_path / "SDP81_bounds.pickle")[0] == "SDP81"
+    # the same source with the chain resident on the device
+    tupd, summd, dsm = fit.fit_source("SDP81", data, nwalkers=32, n_iter_burn=5, n_iter_walk=10, seed=3,
+                                      sampler="device", warm=False)
+    assert tupd[7][0].shape == (10, 32, 4) and np.all(np.isfinite(tupd[7][1]))
+    assert np.all(tupd[7][0] >= b[:, 0]) and np.all(tupd[7][0] <= b[:, 1]) and dsm.iteration == 10
     # 2-component table (T_d column), no warm start
     data2 = data_io.read_data(data_io.FLUX_2COMP)
     tup2, summ2, _ = fit.fit_source("SDP81", data2, ncomp=2, nwalkers=32, n_iter_burn=2, n_iter_walk=3, seed=1,

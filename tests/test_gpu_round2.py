@@ -235,9 +235,15 @@ def test_device_sampler_is_the_host_checker_bit_for_bit(eng, mol):
     _truth_source(eng, mol, cfg)
     p0 = cfg["truth"] + 1e-2 * np.random.RandomState(5).randn(128, 4)
     d = DeviceEnsembleSampler(128, 4, engine=eng, seed=42)
+    assert d.schedule == "dataflow"
     st = d.run_mcmc(p0, 30)
     h = EnsembleSampler(128, 4, eng.lnprob_batch, vectorize=True, seed=42, rng="philox")
     sh = h.run_mcmc(p0, 30)
+    # the same chain under the half-step schedule (propose / solve / accept launches)
+    dh = DeviceEnsembleSampler(128, 4, engine=eng, seed=42, schedule="halfsteps")
+    dh.run_mcmc(p0, 30)
+    assert np.array_equal(dh.get_chain(), d.get_chain()) and np.array_equal(dh.get_log_prob(), d.get_log_prob())
+    assert np.array_equal(dh.acceptance_fraction, d.acceptance_fraction)
     assert np.array_equal(d.get_chain(), h.get_chain())
     assert np.array_equal(d.get_log_prob(), h.get_log_prob())
     assert np.array_equal(st.coords, sh.coords) and np.array_equal(st.log_prob, sh.log_prob)
@@ -250,6 +256,49 @@ def test_device_sampler_is_the_host_checker_bit_for_bit(eng, mol):
     d3 = DeviceEnsembleSampler(128, 4, engine=eng, seed=43)
     d3.run_mcmc(p0, 5)
     assert not np.array_equal(d3.get_chain(), d.get_chain()[:5])
+
+
+def test_dataflow_schedule_is_the_same_chain_at_every_shape(eng, mol):
+    """rx_sampler_run_async_device (one persistent kernel, tasks start when their two input walkers are
+    final, positions versioned in a ring) against rx_sampler_run_device (half-steps): identical chains
+    -- 1024 walkers over more steps than the ring holds versions, walkers spread over the prior box so
+    that slow proposals (maxiter) make the wavefronts run ahead; 16 ensembles with their own sources in
+    the two-waves-per-SIMD regime; two components; without chain storage; resumed."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler, State
+    cfg = workloads.config2(1024)
+    _truth_source(eng, mol, cfg)
+    out = {}
+    for sched in ("dataflow", "halfsteps"):
+        d = DeviceEnsembleSampler(1024, 4, engine=eng, seed=5, schedule=sched)
+        st = d.run_mcmc(cfg["walkers"], 30)
+        st2 = d.run_mcmc(State(st.coords, st.log_prob), 5, store=False)      # resumed, nothing stored
+        out[sched] = (d.get_chain(), d.get_log_prob(), d.acceptance_fraction, st2.coords, st2.log_prob)
+    for a, b in zip(out["dataflow"], out["halfsteps"]):
+        assert np.array_equal(a, b)
+    assert out["dataflow"][0].shape == (30, 1024, 4)
+    # 16 sources x 640 walkers: 5120 tasks per half-step -> two wavefronts per SIMD
+    c3 = workloads.config3(640)
+    _set_config3(eng, c3)
+    out = {}
+    for sched in ("dataflow", "halfsteps"):
+        d = DeviceEnsembleSampler(640, 4, engine=eng, nens=16, ens_src=np.arange(16), seed=6, schedule=sched)
+        d.run_mcmc(c3["walkers"], 4)
+        out[sched] = (d.get_chain(), d.get_log_prob())
+    assert np.array_equal(out["dataflow"][0], out["halfsteps"][0])
+    assert np.array_equal(out["dataflow"][1], out["halfsteps"][1])
+    # two components
+    c4 = workloads.config4(256)
+    W = c4["walkers"].copy()
+    W[128:] = workloads.draw_prior_2comp(c4["bounds"], 128, 17)
+    _truth_source(eng, mol, c4)
+    out = {}
+    for sched in ("dataflow", "halfsteps"):
+        d = DeviceEnsembleSampler(256, 8, engine=eng, seed=8, schedule=sched)
+        d.run_mcmc(W, 14)
+        out[sched] = (d.get_chain(), d.get_log_prob())
+    assert np.array_equal(out["dataflow"][0], out["halfsteps"][0])
+    assert np.array_equal(out["dataflow"][1], out["halfsteps"][1])
+    _truth_source(eng, mol, workloads.config2(8))
 
 
 def test_device_sampler_samples_the_posterior(eng, mol):
