@@ -7,6 +7,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-large-batch --no-sampler --no-config3 --no-sharded"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+# the whole default bench as well (sampler kernels, config 3, sharded shapes): per-kernel time only
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_full -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/trace_full.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1
@@ -34,6 +36,9 @@ json.dump(summary, open("$OUT/pmc_summary.json", "w"), indent=1)
 for f in sorted(glob.glob("$OUT/trace/*/*kernel_stats.csv"))[:1]:
     print(open(f).read())
     open("$OUT/kernel_stats.csv", "w").write(open(f).read())
+for f in sorted(glob.glob("$OUT/trace_full/*/*kernel_stats.csv"))[:1]:
+    print(open(f).read())
+    open("$OUT/kernel_stats_full_bench.csv", "w").write(open(f).read())
 # the stats file averages over every dispatch of the kernel, including the one-walker set-up call
 # of bench.py; split by grid size so that the 1024-walker launches can be read off directly
 for f in sorted(glob.glob("$OUT/trace/*/*kernel_trace.csv"))[:1]:
