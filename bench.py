@@ -250,7 +250,7 @@ def main():
             else:
                 c = workloads.config2(nwk, seed=5678)
                 ens_src = None
-            grp = dist.group.WORLD if (world > 1 and not share) else None
+            grp = dist.group.WORLD if world > 1 else None
             smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp)
             state = smp.run_mcmc(c["walkers"], 1, store=False)              # initial log-probabilities + 1 step
             barrier()
@@ -267,8 +267,11 @@ def main():
                              "ms_per_step": round(d / nst * 1e3, 3),
                              "walker_steps_per_s": round(nwk * nst / d, 1),
                              "solves_per_s": round(nwk * nst * (ndim // 4) / d, 1),
+                             "schedule": "dataflow (one persistent kernel)" if grp is None else
+                                         "half-steps: propose, block evaluation per rank, all-gather, accept",
                              "collective": "none (1 GPU)" if grp is None else
-                                           "all_gather_into_tensor of %d f64 per half-step (RCCL, device)" % (nwk // 2)}
+                                           "all_gather_into_tensor of %d f64 per half-step (%s)"
+                                           % (nwk // 2, "gloo rehearsal, host copies" if share else "RCCL, device")}
             del smp
         if out is not None:
             out["sharded"] = sharded

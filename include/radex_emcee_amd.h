@@ -174,6 +174,10 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
                                 int32_t *d_naccept, double *d_chain, double *d_chain_lnp,
                                 void *stream);
 int rx_sampler_wait(rx_handle *h, void *stream);
+/* Longest time a task of the dataflow sampler polls for its inputs before it raises the abort flag
+ * (default 2000 ms; real waits are milliseconds).  0 makes every wait that is not satisfied at once
+ * give up: the safety path can be exercised on purpose (tests).                                  */
+int rx_set_sampler_timeout_ms(rx_handle *h, double ms);
 int rx_stretch_propose_device(rx_handle *h, int nens, int nwalkers, int ndim, double a,
                               uint64_t seed, int64_t step, int split,
                               const int32_t *d_ens_src, const double *d_coords, double *d_q,

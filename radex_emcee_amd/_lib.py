@@ -25,6 +25,7 @@ EXPORTS = [
     "rx_model_flux_batch_device", "rx_solve_batch", "rx_lubksb_batch", "rx_lubksb_pivots_batch", "rx_escprob_batch", "rx_time_lnprob_device",
     "rx_kernel_name", "rx_set_issue_order", "rx_stretch_propose_device", "rx_stretch_accept_device",
     "rx_sampler_run_device", "rx_set_source_prior", "rx_sampler_run_async_device", "rx_sampler_wait",
+    "rx_set_sampler_timeout_ms",
 ]
 ABI_VERSION = 2
 
@@ -112,6 +113,7 @@ def load():
     L.rx_sampler_run_async_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, u64, i64, C.c_int,
                                               vp, vp, vp, vp, vp, vp, vp]
     L.rx_sampler_wait.argtypes = [vp, vp]
+    L.rx_set_sampler_timeout_ms.argtypes = [vp, C.c_double]
     L.rx_time_lnprob_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
     if L.rx_abi_version() != ABI_VERSION:
         raise EngineLibraryMissing("%s has ABI version %d, this package needs %d: rebuild it"

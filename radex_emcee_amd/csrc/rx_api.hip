@@ -208,6 +208,7 @@ struct rx_handle {
     DevBuf<double> w_hist;           // [RING][N][ndim] positions by version
     uint32_t *d_abort = nullptr;
     uint32_t *h_abort = nullptr;     // pinned mirror, filled by an async copy behind every async run
+    long long sampler_timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock: far beyond any real wait
     unsigned int *d_order_cnt = nullptr;
     int issue_order = 1;             // hand large batches out hottest first (rx_set_issue_order; RX_NO_ORDER=1 at rx_create: off)
     int srcfix_value = -1;
@@ -1012,7 +1013,7 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     A.version = h->w_version.p; A.abort_flag = h->d_abort;
     A.hist = h->w_hist.p; A.done = h->w_version.p + N; A.ring = RING;
     A.chain = d_chain; A.chain_lnp = d_chain_lnp;
-    A.timeout_ticks = 200000000LL;                   // 2 s of the 100 MHz wall clock: far beyond any real wait
+    A.timeout_ticks = h->sampler_timeout_ticks;
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
     HIPCHK(h, hipMemsetAsync(h->d_abort, 0, sizeof(uint32_t), st));
     HIPCHK(h, hipMemsetAsync(h->w_version.p, 0, (N + RING) * sizeof(uint32_t), st));
@@ -1023,6 +1024,13 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
                              hipMemcpyDeviceToDevice, st));                                                  // version nsteps
     HIPCHK(h, hipMemcpyAsync(h->h_abort, h->d_abort, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     return mark_launched(h, st);
+}
+
+int rx_set_sampler_timeout_ms(rx_handle *h, double ms)
+{
+    if (!h || !(ms >= 0.0) || ms > 3.6e6) return RX_E_ARG;
+    h->sampler_timeout_ticks = (long long)(ms * 1e5);          // wall_clock64 ticks at 100 MHz
+    return 0;
 }
 
 int rx_sampler_wait(rx_handle *h, void *stream)

@@ -259,3 +259,6 @@ class Engine:
         import torch
         dev = torch.device("cuda", self.device) if device is None else device
         self._chk(self._L.rx_sampler_wait(self._h, self._stream(dev, stream)), "rx_sampler_wait")
+
+    def set_sampler_timeout_ms(self, ms):
+        self._chk(self._L.rx_set_sampler_timeout_ms(self._h, float(ms)), "rx_set_sampler_timeout_ms")

@@ -510,6 +510,13 @@ class DeviceEnsembleSampler:
         self._mine.fill_(float("-inf"))
         if hi > lo:
             self.backend.evaluate(self, q[lo:hi], self._mine[:hi - lo], None if qsrc is None else qsrc[lo:hi])
+        if self._mine.is_cuda and self._dist.get_backend(self.group) == "gloo":
+            # rehearsal of the control flow on a box whose ranks share one GPU: gloo moves host copies
+            import torch
+            out = torch.empty(self.lnp_q.shape, dtype=torch.float64)
+            self._dist.all_gather_into_tensor(out, self._mine.cpu(), group=self.group)
+            self.lnp_q.copy_(out)
+            return self.lnp_q[:q.shape[0]]
         try:
             self._dist.all_gather_into_tensor(self.lnp_q, self._mine, group=self.group)
         except (RuntimeError, NotImplementedError):

@@ -301,6 +301,25 @@ def test_dataflow_schedule_is_the_same_chain_at_every_shape(eng, mol):
     _truth_source(eng, mol, workloads.config2(8))
 
 
+def test_dataflow_sampler_gives_up_instead_of_hanging(co_path, mol):
+    """Every wait of the dataflow kernel is bounded: with the timeout set to zero a task whose inputs are
+    not final at once raises the abort flag, the grid drains and rx_sampler_wait reports the failure."""
+    from radex_emcee_amd.engine import EngineError
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler
+    e = Engine(co_path)
+    cfg = workloads.config2(256)
+    _truth_source(e, mol, cfg)
+    e.set_sampler_timeout_ms(0.0)
+    d = DeviceEnsembleSampler(256, 4, engine=e, seed=1)
+    with pytest.raises(EngineError, match="waited longer"):
+        d.run_mcmc(cfg["walkers"], 20)
+    e.set_sampler_timeout_ms(2000.0)
+    d = DeviceEnsembleSampler(256, 4, engine=e, seed=1)
+    st = d.run_mcmc(cfg["walkers"], 3)                     # the handle is usable afterwards
+    assert np.all(np.isfinite(st.coords)) and d.get_chain().shape == (3, 256, 4)
+    e.close()
+
+
 def test_device_sampler_samples_the_posterior(eng, mol):
     """Statistical validity on the real likelihood: the chain of the device sampler has the moments of
     the chain the host sampler draws with numpy's generator (emcee's own) -- same target."""
