@@ -301,6 +301,33 @@ def test_dataflow_schedule_is_the_same_chain_at_every_shape(eng, mol):
     _truth_source(eng, mol, workloads.config2(8))
 
 
+@pytest.mark.parametrize("nw,nens,nsteps", [(8, 1, 40), (100, 1, 25), (30, 5, 15), (1500, 1, 3)])
+def test_dataflow_schedule_odd_shapes(eng, mol, nw, nens, nsteps):
+    """Ensemble sizes that are not powers of two (the walker permutation cycle-walks), the smallest legal
+    ensemble, several small ensembles, more steps than ring slots: dataflow == half-steps == host replay."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler, EnsembleSampler
+    cfg = workloads.config2(8)
+    _truth_source(eng, mol, cfg)
+    rs = np.random.RandomState(nw)
+    p0 = cfg["truth"] + 1e-2 * rs.randn(nens, nw, 4)
+    out = {}
+    for sched in ("dataflow", "halfsteps"):
+        d = DeviceEnsembleSampler(nw, 4, engine=eng, nens=nens, seed=77, schedule=sched,
+                                  ens_src=None if nens == 1 else np.zeros(nens, dtype=np.int32))
+        d.run_mcmc(p0 if nens > 1 else p0[0], nsteps)
+        out[sched] = (d.get_chain(), d.get_log_prob())
+    assert np.array_equal(out["dataflow"][0], out["halfsteps"][0])
+    assert np.array_equal(out["dataflow"][1], out["halfsteps"][1])
+    if nens == 1 and nw <= 100:
+        h = EnsembleSampler(nw, 4, eng.lnprob_batch, vectorize=True, seed=77, rng="philox")
+        h.run_mcmc(p0[0], nsteps)
+        assert np.array_equal(h.get_chain(), out["dataflow"][0])
+    d = DeviceEnsembleSampler(nw, 4, engine=eng, nens=nens, seed=77,
+                              ens_src=None if nens == 1 else np.zeros(nens, dtype=np.int32))
+    st = d.run_mcmc(p0 if nens > 1 else p0[0], 0)          # zero steps: the state comes back unchanged
+    assert np.array_equal(st.coords.reshape(-1, 4), p0.reshape(-1, 4)) and d.get_chain().shape[0] == 0
+
+
 def test_dataflow_sampler_gives_up_instead_of_hanging(co_path, mol):
     """Every wait of the dataflow kernel is bounded: with the timeout set to zero a task whose inputs are
     not final at once raises the abort flag, the grid drains and rx_sampler_wait reports the failure."""
