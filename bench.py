@@ -131,8 +131,13 @@ def main():
     share = os.environ.get("RX_BENCH_SHARE_GPU") == "1"
     if share:
         local = 0
-    if world > 1:
+    # RX_BENCH_FORCE_DIST=1: initialise the process group and run every collective even with ONE rank
+    # (nccl = RCCL with world size 1): exercises the N > 1 code path on a one-GPU box
+    force = os.environ.get("RX_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -167,11 +172,11 @@ def main():
 
     def step():
         eng.lnprob_batch_torch(P, lnp, st, nit, stream=stream)
-        if world > 1:
+        if use_dist:
             gather(lnp_all, lnp)                   # log-probabilities of the whole batch on every rank
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -183,7 +188,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -250,7 +255,7 @@ def main():
             else:
                 c = workloads.config2(nwk, seed=5678)
                 ens_src = None
-            grp = dist.group.WORLD if world > 1 else None
+            grp = dist.group.WORLD if use_dist else None
             smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp)
             state = smp.run_mcmc(c["walkers"], 1, store=False)              # initial log-probabilities + 1 step
             barrier()
@@ -258,7 +263,7 @@ def main():
             smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
             barrier()
             d = time.perf_counter() - ts
-            if world > 1:
+            if use_dist:
                 tm = torch.tensor([d], dtype=torch.float64, device="cpu" if share else dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 d = float(tm.item())
@@ -404,7 +409,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, truth_flux)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

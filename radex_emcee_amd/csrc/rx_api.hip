@@ -941,14 +941,17 @@ int rx_sampler_run_device(rx_handle *h, int nens, int nwalkers, int ncomp, doubl
     if (solve_ms_out) {
         *solve_ms_out = 0.0;
         ev.resize((size_t)4 * nsteps, nullptr);
-        for (auto &e : ev) HIPCHK(h, hipEventCreate(&e));
     }
     auto drop_events = [&]() { for (auto e : ev) if (e) (void)hipEventDestroy(e); };
+    for (auto &e : ev) {
+        hipError_t ee = hipEventCreate(&e);
+        if (ee != hipSuccess) { drop_events(); return hip_fail(h, ee, "hipEventCreate"); }
+    }
     for (int s = 0; s < nsteps; ++s) {
         for (int split = 0; split < 2; ++split) {
             int rc = rx_stretch_propose_device(h, nens, nwalkers, ndim, a, seed, step0 + s, split, d_ens_src, d_coords,
                                                h->w_q.p, h->w_factor.p, h->w_widx.p, d_ens_src ? h->w_qsrc.p : nullptr, st);
-            if (rc) return rc;
+            if (rc) { drop_events(); return rc; }
             const size_t ei = (size_t)4 * s + 2 * split;
             rc = lnprob_device(h, (int)nq, ncomp, h->w_q.p, d_ens_src ? h->w_qsrc.p : nullptr, h->w_lnpq.p,
                                h->w_qstatus.p, h->w_qniter.p, st, solve_ms_out ? ev[ei] : nullptr,
@@ -956,10 +959,12 @@ int rx_sampler_run_device(rx_handle *h, int nens, int nwalkers, int ncomp, doubl
             if (rc) { drop_events(); return rc; }
             rc = rx_stretch_accept_device(h, nens, nwalkers, ndim, seed, step0 + s, split, h->w_q.p, h->w_lnpq.p,
                                           h->w_factor.p, h->w_widx.p, d_coords, d_lnp, d_naccept, st);
-            if (rc) return rc;
+            if (rc) { drop_events(); return rc; }
         }
-        if (d_chain) HIPCHK(h, hipMemcpyAsync(d_chain + (size_t)s * N * ndim, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));
-        if (d_chain_lnp) HIPCHK(h, hipMemcpyAsync(d_chain_lnp + (size_t)s * N, d_lnp, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        hipError_t ce = hipSuccess;
+        if (d_chain) ce = hipMemcpyAsync(d_chain + (size_t)s * N * ndim, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st);
+        if (ce == hipSuccess && d_chain_lnp) ce = hipMemcpyAsync(d_chain_lnp + (size_t)s * N, d_lnp, N * sizeof(double), hipMemcpyDeviceToDevice, st);
+        if (ce != hipSuccess) { drop_events(); return hip_fail(h, ce, "rx_sampler_run_device: chain copy"); }
     }
     if (solve_ms_out && nsteps > 0) {
         hipError_t e = hipStreamSynchronize(st);

@@ -449,6 +449,7 @@ class DeviceEnsembleSampler:
             self.qsrc = torch.empty(nq, dtype=torch.int32, device=dev)
         self.group = group
         self.world = 1
+        self._sharded = bool(group is not None or sharded)   # the collective path, even on a group of one rank
         if group is not None or sharded:
             import torch.distributed as dist
             self.world = dist.get_world_size(group)
@@ -502,7 +503,7 @@ class DeviceEnsembleSampler:
 
     # --- evaluation of one batch of proposals (sharded over the group when there is one) --------------
     def _evaluate(self, q, qsrc):
-        if self.world == 1:
+        if not self._sharded:
             out = self.lnp_q[:q.shape[0]]
             self.backend.evaluate(self, q, out, qsrc)
             return out
@@ -562,12 +563,12 @@ class DeviceEnsembleSampler:
         if store and nsteps > 0:
             chain = torch.empty(nsteps, self.N, self.ndim, dtype=torch.float64, device=self.coords.device)
             chain_lnp = torch.empty(nsteps, self.N, dtype=torch.float64, device=self.coords.device)
-        if self.engine is not None and self.world == 1 and self.schedule == "dataflow" and not self.time_solves:
+        if self.engine is not None and not self._sharded and self.schedule == "dataflow" and not self.time_solves:
             self.engine.sampler_run_async_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed,
                                                 self.step_counter, nsteps, self.coords, self.lnp, self.naccept,
                                                 chain, chain_lnp, ens_src=self.ens_src)
             self.engine.sampler_wait(self.coords.device)
-        elif self.engine is not None and self.world == 1:
+        elif self.engine is not None and not self._sharded:
             # one call enqueues every kernel of every step on the current stream
             self.last_solve_ms = self.engine.sampler_run_torch(
                 self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed, self.step_counter, nsteps,
