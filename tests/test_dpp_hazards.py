@@ -1,17 +1,41 @@
-"""The hand-written v_*_dpp instructions of the linear solve read a DPP source that a VALU
-instruction must not have written in the two preceding wait states; hipcc pads nothing inside or
-around asm statements, so the disassembly of every instantiation is checked (CPU only: hipcc
-cross-compiles).  A violation made rx_lubksb_kernel<32> return wrong solutions on the GPU."""
+"""Checks on the disassembly of every kernel instantiation (CPU only: hipcc cross-compiles).
+
+1. The hand-written v_*_dpp instructions of the linear solve read a DPP source that a VALU instruction
+   must not have written in the two preceding wait states; hipcc pads nothing inside or around asm
+   statements.  A violation made rx_lubksb_kernel<32> return wrong solutions on the GPU.
+2. The persistent item / task loops of rx_solve_kernel and rx_sampler_kernel must be scalar loops: in
+   the exec-masked form hipcc 7.2 sometimes builds, wavefronts have been seen to loop for ever."""
 import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_no_dpp_read_after_write_hazard():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_dpp_hazards.py"), "-"],
+@pytest.fixture(scope="module")
+def asm_path(tmp_path_factory):
+    d = tmp_path_factory.mktemp("rxasm")
+    src = os.path.join(ROOT, "radex_emcee_amd", "csrc", "rx_api.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+           "-mllvm", "-pragma-unroll-threshold=4000000", "-mllvm", "-disable-machine-licm", "-save-temps", "-c",
+           "-o", "/dev/null", src]
+    subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
+    return str(d / "rx_api-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def test_no_dpp_read_after_write_hazard(asm_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_dpp_hazards.py"), asm_path],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert "0 hazard(s)" in last and not last.startswith("0 DPP"), last
+
+
+def test_item_loops_are_scalar_loops(asm_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_item_loop.py"), asm_path],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "0 with an exec-masked item loop" in last and not last.startswith("0 persistent"), last
