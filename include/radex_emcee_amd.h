@@ -139,6 +139,9 @@ int rx_lnprob_batch_device(rx_handle *h, int N, int ncomp, const double *d_param
  * either way.  Default on; the environment variable RX_NO_ORDER=1, read once by rx_create,
  * starts a handle with it off.                                                             */
 int rx_set_issue_order(rx_handle *h, int hottest_first);
+/* Scheduling only as well: wavefronts per SIMD of the solve launches.  0 (default) = chosen from the
+ * batch size, 1 = lowest latency per walker, 2 = highest throughput.        */
+int rx_set_waves_per_simd(rx_handle *h, int waves);
 
 /* The caller of lnprob on the device: emcee's StretchMove (a = 2) inside RedBlueMove with two
  * random halves, as driven by EnsembleSampler.run_mcmc in emcee/emcee_radex.py:483-499 and

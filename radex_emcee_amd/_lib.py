@@ -25,7 +25,7 @@ EXPORTS = [
     "rx_model_flux_batch_device", "rx_solve_batch", "rx_lubksb_batch", "rx_lubksb_pivots_batch", "rx_escprob_batch", "rx_time_lnprob_device",
     "rx_kernel_name", "rx_set_issue_order", "rx_stretch_propose_device", "rx_stretch_accept_device",
     "rx_sampler_run_device", "rx_set_source_prior", "rx_sampler_run_async_device", "rx_sampler_wait",
-    "rx_set_sampler_timeout_ms",
+    "rx_set_sampler_timeout_ms", "rx_set_waves_per_simd",
 ]
 ABI_VERSION = 2
 
@@ -96,6 +96,7 @@ def load():
     L.rx_lnprob_batch.argtypes = [vp, C.c_int, dp, ip, dp, ip, ip]
     L.rx_lnprob_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.rx_set_issue_order.argtypes = [vp, C.c_int]
+    L.rx_set_waves_per_simd.argtypes = [vp, C.c_int]
     L.rx_set_source_prior.argtypes = [vp, C.c_int, C.c_int]
     u64, i64 = C.c_uint64, C.c_int64
     L.rx_stretch_propose_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, u64, i64, C.c_int,

@@ -210,6 +210,7 @@ struct rx_handle {
     uint32_t *h_abort = nullptr;     // pinned mirror, filled by an async copy behind every async run
     long long sampler_timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock: far beyond any real wait
     unsigned int *d_order_cnt = nullptr;
+    int force_occ = 0;               // 0: choose by batch size; 1 / 2: wavefronts per SIMD (rx_set_waves_per_simd)
     int issue_order = 1;             // hand large batches out hottest first (rx_set_issue_order; RX_NO_ORDER=1 at rx_create: off)
     int srcfix_value = -1;
     size_t srcfix_filled = 0;
@@ -450,8 +451,11 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     const int ncomp = (a.mode == RXK_MODE_SOLVE) ? 1 : a.ncomp;
     const long items = (long)a.N * ncomp;
     long blocks = (items + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK;
-    // one wavefront per SIMD until the batch exceeds the chip, then the 2-wave/SIMD build
-    const int occ = (blocks > (long)h->num_cu && h->blocks_per_cu2 >= 2) ? 2 : 1;
+    // one wavefront per SIMD (6.1 us per iteration each) up to ~5 rounds of the chip, then the 2-wave/SIMD
+    // build (two at 10.5 us): measured crossover between 4096 and 6144 walkers (scripts/occ_crossover.py) --
+    // below it the launch is mostly the 200-iteration walkers, which run faster alone on their SIMD
+    int occ = (items > 5L * h->num_cu * RXK_WAVES_PER_BLOCK && h->blocks_per_cu2 >= 2) ? 2 : 1;
+    if (h->force_occ == 1 || (h->force_occ == 2 && h->blocks_per_cu2 >= 2)) occ = h->force_occ;
     const long cap = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
@@ -664,6 +668,13 @@ int rx_set_source_prior(rx_handle *h, int src, int enabled)
     HIPCHK(h, hipSetDevice(h->device));
     if (h->in_flight) { HIPCHK(h, hipEventSynchronize(h->ev_done)); h->in_flight = false; }
     HIPCHK(h, hipMemcpy(h->d_srcs + src, &h->h_srcs[src], sizeof(RxSourceDev), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int rx_set_waves_per_simd(rx_handle *h, int waves)
+{
+    if (!h || waves < 0 || waves > 2) return RX_E_ARG;
+    h->force_occ = waves;
     return 0;
 }
 

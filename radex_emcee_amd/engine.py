@@ -262,3 +262,7 @@ class Engine:
 
     def set_sampler_timeout_ms(self, ms):
         self._chk(self._L.rx_set_sampler_timeout_ms(self._h, float(ms)), "rx_set_sampler_timeout_ms")
+
+    def set_waves_per_simd(self, waves=0):
+        """Scheduling of the solve launches: 0 = automatic, 1 = one wavefront per SIMD, 2 = two."""
+        self._chk(self._L.rx_set_waves_per_simd(self._h, int(waves)), "rx_set_waves_per_simd")
