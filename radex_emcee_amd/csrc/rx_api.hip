@@ -1017,7 +1017,10 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     if (!h->h_abort) { HIPCHK(h, hipHostMalloc(&h->h_abort, sizeof(uint32_t))); *h->h_abort = 0; }
     // few tasks per half-step: one wavefront per SIMD (lowest latency per task), the whole chip so that
     // wavefronts can run ahead of a slow task; many: two per SIMD (throughput)
-    const int occ = (nq > (size_t)2 * h->num_cu * RXK_WAVES_PER_BLOCK && h->blocks_per_cu2 >= 2) ? 2 : 1;
+    // (measured crossover, scripts/occ_crossover_sampler.py: 2048 walkers 0.77 ms per step with one wavefront
+    // per SIMD against 0.86 with two, 4096 walkers 1.17 against 1.00)
+    int occ = (nq > (size_t)3 * h->num_cu * RXK_WAVES_PER_BLOCK / 2 && h->blocks_per_cu2 >= 2) ? 2 : 1;
+    if (h->force_occ == 1 || (h->force_occ == 2 && h->blocks_per_cu2 >= 2)) occ = h->force_occ;
     long blocks = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     const long need = (long)((2 * nq * (size_t)nsteps + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK);
     if (blocks > need) blocks = need;
