@@ -47,11 +47,12 @@ def build(fast: bool = False, force: bool = False) -> str:
 
 
 def kernel_source_sha256() -> str:
-    """Hash of everything the device code is compiled from (sources + build flags): profiles record it,
-    and bench.py refuses a PMC summary that was measured on other kernel sources."""
+    """Hash of everything the DEVICE code is compiled from (kernel sources, table layouts, build flags;
+    not the host side of the library): profiles record it, and bench.py refuses a PMC summary that was
+    measured on other kernel sources."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rx_kernel.hip.inc", "rx_sampler.hip.inc", "rx_api.hip", "rx_tables.h", "Makefile"):
+    for f in ("rx_kernel.hip.inc", "rx_sampler.hip.inc", "rx_tables.h", "Makefile"):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()
