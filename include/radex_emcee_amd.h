@@ -176,7 +176,7 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
                                 const int32_t *d_ens_src, double *d_coords, double *d_lnp,
                                 int32_t *d_naccept, double *d_chain, double *d_chain_lnp,
                                 void *stream);
-int rx_sampler_wait(rx_handle *h, void *stream);
+int rx_sampler_wait(rx_handle *h, void *stream);   /* after EVERY async run: a later run resets the flag */
 /* Longest time a task of the dataflow sampler polls for its inputs before it raises the abort flag
  * (default 2000 ms; real waits are milliseconds).  0 makes every wait that is not satisfied at once
  * give up: the safety path can be exercised on purpose (tests).                                  */
