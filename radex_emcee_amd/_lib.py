@@ -52,9 +52,11 @@ def kernel_source_sha256() -> str:
     measured on other kernel sources."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rx_kernel.hip.inc", "rx_sampler.hip.inc", "rx_tables.h", "Makefile"):
+    for f in ("rx_kernel.hip.inc", "rx_sampler.hip.inc", "rx_tables.h"):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.join(CSRC, "Makefile")) as fh:          # the compiler flags of the product library
+        h.update("".join(l for l in fh if l.startswith("CXXFLAGS")).encode())
     return h.hexdigest()
 
 
