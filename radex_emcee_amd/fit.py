@@ -79,11 +79,16 @@ def load_result(path):
 
 
 def fit_source(source, data, ncomp=1, nwalkers=None, n_iter_burn=100, n_iter_walk=None, seed=None,
-               engine=None, warm=True, lnprob_wrapper=None, sampler="host"):
+               engine=None, warm=True, lnprob_wrapper=None, sampler=None):
     """One source end to end.  Defaults are the reference's: 100 walkers x (100 + 500) steps for
     one component, 400 x (100 + 1000) for two (emcee_radex.py:472-474, 2comp:548-550).
-    sampler="device": the chain runs in HBM (DeviceEnsembleSampler: propose / solve / accept kernels,
-    counter-based random stream); "host": numpy stretch move + one rx_lnprob_batch per half-step."""
+    sampler="device" (default): the chain runs in HBM (DeviceEnsembleSampler, dataflow schedule,
+    counter-based random stream); "host" (default when an lnprob_wrapper is given): numpy stretch move
+    with numpy's generator + one rx_lnprob_batch per half-step."""
+    if sampler is None:
+        sampler = "host" if lnprob_wrapper is not None else "device"
+    if sampler not in ("device", "host"):
+        raise ValueError("sampler must be 'device' or 'host'")
     if ncomp == 1:
         z, _lw, Jup, flux, eflux = data_io.get_source(source, data)
         T_d, p0 = None, P0_1COMP

@@ -98,7 +98,8 @@ def test_fit_source_end_to_end(tmp_path):
     """table reader -> set-up -> warm start -> sampler -> result tuple -> summary."""
     from radex_emcee_amd import data_io, fit
     data = data_io.read_data()
-    tup, summ, sampler = fit.fit_source("SDP81", data, nwalkers=32, n_iter_burn=5, n_iter_walk=10, seed=3)
+    tup, summ, sampler = fit.fit_source("SDP81", data, nwalkers=32, n_iter_burn=5, n_iter_walk=10, seed=3,
+                                        sampler="host")
     assert tup[0] == "SDP81" and len(tup) == 8
     chain, lnp = tup[7]
     assert chain.shape == (10, 32, 4) and lnp.shape == (10, 32) and np.all(np.isfinite(lnp))
@@ -117,6 +118,7 @@ def test_fit_source_end_to_end(tmp_path):
     assert np.all(tupd[7][0] >= b[:, 0]) and np.all(tupd[7][0] <= b[:, 1]) and dsm.iteration == 10
     # 2-component table (T_d column), no warm start
     data2 = data_io.read_data(data_io.FLUX_2COMP)
-    tup2, summ2, _ = fit.fit_source("SDP81", data2, ncomp=2, nwalkers=32, n_iter_burn=2, n_iter_walk=3, seed=1,
-                                    warm=False)
+    tup2, summ2, smp2 = fit.fit_source("SDP81", data2, ncomp=2, nwalkers=32, n_iter_burn=2, n_iter_walk=3, seed=1,
+                                       warm=False)                       # default: the sampler on the device
+    assert type(smp2).__name__ == "DeviceEnsembleSampler"
     assert len(tup2) == 9 and tup2[3] == 34.0 and tup2[8][0].shape == (3, 32, 8) and len(summ2) == 2
