@@ -278,6 +278,38 @@ def main():
                                            "all_gather_into_tensor of %d f64 per half-step (%s)"
                                            % (nwk // 2, "gloo rehearsal, host copies" if share else "RCCL, device")}
             del smp
+        if not args.no_config3:
+            # BASELINE configs[2] across GPUs: independent ensembles need no exchange at all -- rank r advances
+            # its 16 / N sources (1024 walkers each) with the dataflow sampler; replicas, no collective
+            c3b = workloads.config3(1024, init="ball")
+            per = max(1, 16 // world)
+            mine = list(range(rank * per, min(16, (rank + 1) * per)))
+            d = 0.0
+            if mine:
+                e3 = Engine(device=local)
+                for k in mine:
+                    s = c3b["sources"][k]
+                    e3.set_source(s["tbg"], s["Jup"], s["flux"], s["eflux"], s["bounds"], src=k - mine[0])
+                sm = DeviceEnsembleSampler(1024, 4, engine=e3, nens=len(mine), ens_src=np.arange(len(mine)), seed=11)
+                st3 = sm.run_mcmc(c3b["walkers"][mine], 2, store=False)
+                barrier()
+                ts = time.perf_counter()
+                sm.run_mcmc(State(st3.coords, st3.log_prob), 20, store=False)
+                torch.cuda.synchronize()
+                d = time.perf_counter() - ts
+                e3.close()
+            else:
+                barrier()
+            if use_dist:
+                tm = torch.tensor([d], dtype=torch.float64, device="cpu" if share else dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                d = float(tm.item())
+            nsrc = min(16, per * world)
+            sharded["config3_replicas"] = {"sources": nsrc, "sources_per_rank": per, "walkers": 1024 * nsrc, "steps": 20,
+                                           "scaling": "strong", "ms_per_step": round(d / 20 * 1e3, 3),
+                                           "walker_steps_per_s": round(1024 * nsrc * 20 / d, 1),
+                                           "schedule": "dataflow, one persistent kernel per rank",
+                                           "collective": "none: the sources' ensembles are independent (replicas)"}
         if out is not None:
             out["sharded"] = sharded
         eng.set_source(cfg["tbg"], cfg["Jup"], truth_flux, 0.1 * truth_flux, cfg["bounds"])
