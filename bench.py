@@ -16,7 +16,8 @@ buffers) makes the full vector available on every rank before the stretch move w
 collective is INSIDE the timed region.  Per-GPU work is fixed -> "scaling": "weak"; at N = 1 the
 collective degenerates and the line is the single-GPU number.  The strong-scaling shapes of
 BASELINE configs[3] and [4] (2048 two-component walkers; 65536 walkers) are timed as well, through
-the device-resident sampler with the same sharding ("sharded": {...}, walker-steps/s).
+the device-resident sampler with the same sharding ("sharded": {...}, walker-steps/s), and the 16
+independent ensembles of configs[2] are dealt out 16/N per rank as replicas (no collective).
 Rank 0 prints ONE JSON line.
 """
 import argparse
