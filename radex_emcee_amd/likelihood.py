@@ -142,3 +142,29 @@ def lnprob(p, Jup, flux, eflux, bounds=None, T_d=None):
     ncomp = p.size // 4
     eng.set_source(eng._tbg, np.asarray(np.int_(Jup)), flux, eflux, bounds, ncomp, T_d, src=0)
     return float(eng.lnprob_batch(p[None, :])[0])
+
+
+def EnsembleSampler(nwalkers, ndim, log_prob_fn, args=None, kwargs=None, pool=None, seed=0, **options):
+    """Call-site compatible with the reference's
+        sampler = emcee.EnsembleSampler(nwalkers, ndim, lnprob, args=(Jup, flux, eflux),
+                                        kwargs={'bounds': bounds[, 'T_d': T_d]}, pool=pool)
+    (emcee_radex.py:483-488, emcee_radex_2comp.py:557-563).  When `log_prob_fn` is this module's
+    `lnprob`, its closure arguments become source slot 0 of the process's engine (`init_radex`) and the
+    chain runs on the GPU (sampler.DeviceEnsembleSampler: run_mcmc / reset / get_chain / get_log_prob as
+    the scripts use them); `pool` is accepted and ignored -- the batch IS the parallelism.  Any other
+    function gets the host sampler (one call per walker, like emcee without vectorize)."""
+    from . import sampler as _s
+    if log_prob_fn is lnprob:
+        eng = globals()["R"]
+        if eng is None:
+            raise RuntimeError("call init_radex(tbg) first")
+        a = tuple(args or ())
+        kw = dict(kwargs or {})
+        if len(a) != 3:
+            raise ValueError("lnprob takes args=(Jup, flux, eflux)")
+        Jup, flux, eflux = a
+        ncomp = int(ndim) // 4
+        eng.set_source(eng._tbg, np.asarray(np.int_(Jup)), np.asarray(flux, dtype=np.float64),
+                       np.asarray(eflux, dtype=np.float64), kw.get("bounds"), ncomp, kw.get("T_d"), src=0)
+        return _s.DeviceEnsembleSampler(nwalkers, ndim, engine=eng, seed=seed, **options)
+    return _s.EnsembleSampler(nwalkers, ndim, log_prob_fn, args=args, kwargs=kwargs, pool=pool, seed=seed, **options)

@@ -77,6 +77,34 @@ def test_per_walker_functions(mol):
     assert likelihood.lnlike([4.0, 4.5, 15.0, -10.0], cfg["Jup"], truth, 0.1 * truth) == -np.inf
 
 
+def test_reference_call_site_runs_on_the_device(mol):
+    """emcee_radex.py:483-499 verbatim but for the import: EnsembleSampler(nwalkers, ndim, lnprob, args=(Jup,
+    flux, eflux), kwargs={'bounds': bounds}, pool=pool); run_mcmc; reset; run_mcmc; get_chain / get_log_prob."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler
+    cfg = workloads.config1(64)
+    likelihood.R = None
+    R = likelihood.init_radex(cfg["tbg"])
+    truth = likelihood.model_lvg(cfg["Jup"], cfg["truth"], R)
+    Jup, flux, eflux, bounds = cfg["Jup"], truth, 0.1 * truth, cfg["bounds"]
+    nwalkers, ndim, pool = 64, 4, None
+    sampler = likelihood.EnsembleSampler(nwalkers, ndim, likelihood.lnprob, args=(Jup, flux, eflux),
+                                         kwargs={'bounds': bounds}, pool=pool)
+    assert isinstance(sampler, DeviceEnsembleSampler)
+    state = sampler.run_mcmc(cfg["walkers"], 5, progress=False)
+    sampler.reset()
+    sampler.run_mcmc(state, 8, progress=False)
+    chain, lnprobability, flatchain = sampler.get_chain(), sampler.get_log_prob(), sampler.get_chain(flat=True)
+    assert chain.shape == (8, 64, 4) and lnprobability.shape == (8, 64) and flatchain.shape == (512, 4)
+    # every stored log-probability is what lnprob returns for the stored position
+    for w in (0, 17, 63):
+        assert lnprobability[-1, w] == likelihood.lnprob(chain[-1, w], Jup, flux, eflux, bounds=bounds)
+    # a foreign log-probability function falls back to the host sampler
+    host = likelihood.EnsembleSampler(8, 2, lambda p: -0.5 * float(np.sum(p * p)))
+    host.run_mcmc(np.random.RandomState(0).randn(8, 2), 3)
+    assert host.get_chain().shape == (3, 8, 2)
+    likelihood.R.close(); likelihood.R = None
+
+
 def test_sampler_on_gpu_matches_sampler_on_oracle(mol):
     """BASELINE config 1 in miniature: 400 walkers around the truth, stretch move, GPU lnprob per
     half-step vs the same sampler fed by the CPU oracle."""
