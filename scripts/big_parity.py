@@ -20,6 +20,11 @@ print("finite both: %d ; finite mismatch: %d" % (fin.sum(), (np.isfinite(rl) != 
 same = fin & (nit == rnit)
 d = np.abs(lnp[same] - rl[same]) / np.maximum(np.abs(rl[same]), 1.0)
 print("max rel dev of lnprob (same niter): %.3e ; 99.9th pct %.3e" % (d.max(), np.percentile(d, 99.9)))
+for name, code in (("converged (RX_OK)", 0), ("maxiter (RX_MAXITER)", 1)):
+    m = same & (rst == code)
+    dd = np.abs(lnp[m] - rl[m]) / np.maximum(np.abs(rl[m]), 1.0)
+    print("  %-22s %7d walkers: max %.3e ; 99.9th pct %.3e ; above 1e-4: %d ; above 1e-5: %d"
+          % (name, m.sum(), dd.max(), np.percentile(dd, 99.9), int((dd > 1e-4).sum()), int((dd > 1e-5).sum())))
 diff = fin & (nit != rnit)
 if diff.any():
     d2 = np.abs(lnp[diff] - rl[diff]) / np.maximum(np.abs(rl[diff]), 1.0)
