@@ -338,8 +338,16 @@ def test_dataflow_sampler_gives_up_instead_of_hanging(co_path, mol):
     _truth_source(e, mol, cfg)
     e.set_sampler_timeout_ms(0.0)
     d = DeviceEnsembleSampler(256, 4, engine=e, seed=1)
+    d.fallback = False
     with pytest.raises(EngineError, match="waited longer"):
         d.run_mcmc(cfg["walkers"], 20)
+    # by default the sampler repeats an abandoned run under the half-step schedule: the same chain
+    d = DeviceEnsembleSampler(256, 4, engine=e, seed=1)
+    with pytest.warns(UserWarning, match="abandoned"):
+        d.run_mcmc(cfg["walkers"], 6)
+    ref = DeviceEnsembleSampler(256, 4, engine=e, seed=1, schedule="halfsteps")
+    ref.run_mcmc(cfg["walkers"], 6)
+    assert np.array_equal(d.get_chain(), ref.get_chain()) and np.array_equal(d.acceptance_fraction, ref.acceptance_fraction)
     e.set_sampler_timeout_ms(2000.0)
     d = DeviceEnsembleSampler(256, 4, engine=e, seed=1)
     st = d.run_mcmc(cfg["walkers"], 3)                     # the handle is usable afterwards
