@@ -8,6 +8,11 @@ walkers uniform in the prior box), parameters already resident in HBM.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with no WORLD_SIZE in the environment starts the N rank processes itself (one per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set for them; the parent never touches a GPU and exits with the worst
+return code); under torch.distributed.run the ranks already exist.  Rank 0 prints the line; "n_gpus" is the
+world size as an all_reduce of ones over the process group found it.
+
 N = 1: the batch is the 1024 walkers of config 2.
 N > 1: the partitioning north_star names -- the global batch (N x 1024 walkers; rank r's contiguous
 block is the config-2 draw with seed 1234 + r) is sharded in blocks of 1024, every rank evaluates its
@@ -15,8 +20,12 @@ block on its GPU and ONE all_gather_into_tensor of the log-probabilities (RCCL o
 buffers) makes the full vector available on every rank before the stretch move would run: the
 collective is INSIDE the timed region.  Per-GPU work is fixed -> "scaling": "weak"; at N = 1 the
 collective degenerates and the line is the single-GPU number.  The strong-scaling shapes of
-BASELINE configs[3] and [4] (2048 two-component walkers; 65536 walkers) are timed as well, through
-the device-resident sampler with the same sharding ("sharded": {...}, walker-steps/s), and the 16
+BASELINE configs[3] and [4] (2048 two-component walkers; 65536 walkers: ONE ensemble each, whatever N)
+are timed through the device-resident sampler ("sharded": {...}, walker-steps/s): first on rank 0's GPU
+alone (the one-GPU dataflow kernel -- the number every multi-GPU schedule has to beat), then across the N
+ranks with the peer-write dataflow schedule (every rank's persistent kernel publishes into all replicas
+over xGMI, no collective) and with the half-step schedule north_star spells out (block evaluation per rank,
+ONE all_gather of log-probabilities per half-step), each with its speedup over the one-GPU number.  The 16
 independent ensembles of configs[2] are dealt out 16/N per rank as replicas (no collective).
 Rank 0 prints ONE JSON line.
 """
@@ -83,6 +92,50 @@ def cpu_baseline(cfg, truth_flux, seconds=15.0):
                       "%d walkers on 1 thread" % (reps, cores, dta, n1)}
 
 
+def config0_device(device):
+    """BASELINE configs[0] (the reference's own CPU-runnable case: APM08279+5255 stand-in, 1 component, 400
+    walkers x 200 steps) through the reference's call site -- likelihood.init_radex + likelihood.EnsembleSampler(
+    nwalkers, ndim, lnprob, args=(Jup, flux, eflux), kwargs={'bounds': bounds}) + run_mcmc, emcee_radex.py:480-494
+    -- with the chain on the device.  Wall time of run_mcmc including the initial log-probabilities."""
+    from radex_emcee_amd import likelihood as L, workloads
+    c = workloads.config1(400)
+    R = L.init_radex(c["tbg"], device=device)
+    truth = L.model_lvg(c["Jup"], c["truth"], R)
+    sampler = L.EnsembleSampler(400, 4, L.lnprob, args=(c["Jup"], truth, 0.1 * truth), kwargs={"bounds": c["bounds"]}, seed=0)
+    sampler.run_mcmc(c["walkers"], 2, store=False)                              # (first launch: module load)
+    sampler.reset()
+    t0 = time.perf_counter()
+    sampler.run_mcmc(c["walkers"], 200)
+    d = time.perf_counter() - t0
+    return {"workload": "BASELINE configs[0]: APM08279+5255 stand-in (z=3.911, Jup 1,2,4,6,9,10,11), 1 component, "
+                        "400 walkers x 200 steps through likelihood.EnsembleSampler (the reference's call site), chain on the device",
+            "wall_s": round(d, 4), "walker_steps_per_s": round(400 * 200 / d, 1),
+            "acceptance": round(float(sampler.acceptance_fraction.mean()), 3),
+            "schedule": sampler.last_schedule}
+
+
+def config0_cpu(cores):
+    """The same 400 x 200 chain length on the CPU oracle (kind 'port') through the host sampler: one batched call of
+    200 proposals per half-step on `cores` OpenMP threads = the reference's Pool(cores).map over a half-ensemble."""
+    from oracle import oracle as O
+    from radex_emcee_amd import workloads
+    from radex_emcee_amd.molecule import default_molfile
+    from radex_emcee_amd.sampler import EnsembleSampler
+    c = workloads.config1(400)
+    mol = O.Molecule(default_molfile())
+    src0 = O.Source(c["tbg"], c["Jup"], np.ones(len(c["Jup"])), np.ones(len(c["Jup"])), c["bounds"])
+    truth = O.model_flux_batch(mol, src0, c["truth"][None, :])[0][0]
+    src = O.Source(c["tbg"], c["Jup"], truth, 0.1 * truth, c["bounds"])
+    fn = lambda P: O.lnprob_batch(mol, src, P, nthreads=cores)[0]
+    smp = EnsembleSampler(400, 4, fn, vectorize=True, seed=0)
+    t0 = time.perf_counter()
+    smp.run_mcmc(c["walkers"], 200, progress=False, store=False)
+    d = time.perf_counter() - t0
+    return {"config0_wall_s": round(d, 3), "config0_walker_steps_per_s": round(400 * 200 / d, 1),
+            "config0_sample": "BASELINE configs[0] in full: 400 walkers x 200 steps, host stretch move + the oracle on "
+                              "%d OpenMP threads (one batch of 200 proposals per half-step)" % cores}
+
+
 def _measured_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/latest_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate passes by
@@ -106,6 +159,25 @@ def _measured_traffic():
         return None
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: N child processes, one rank each, created BEFORE anything in
+    this process touches a GPU (no torch import here); rank 0 inherits stdout and prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +190,8 @@ def main():
     ap.add_argument("--no-config3", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -148,6 +222,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nw = args.walkers
+    n_confirmed = 1
+    if use_dist:                                       # the world size as the process group itself counts it
+        ones = torch.ones(1, dtype=torch.float64, device="cpu" if share else dev)
+        dist.all_reduce(ones)
+        n_confirmed = int(round(float(ones.item())))
+        assert n_confirmed == world, (n_confirmed, world)
+        if args.gpus != world and rank == 0:
+            print("bench.py: --gpus %d but the process group has %d ranks; reporting %d" % (args.gpus, world, world),
+                  file=sys.stderr)
 
     # this rank's block of the global batch: same distribution, rank-specific seed
     cfg = workloads.config2(nw, seed=1234 + rank)
@@ -214,7 +297,7 @@ def main():
         fl = flops_per_eval(niter_mean) * solved
         out = {
             "metric": "walker-lnlike evals/sec (1024 walkers, CO 1-comp)",
-            "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "evals/s", "n_gpus": n_confirmed, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
@@ -231,7 +314,10 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "path is fp64-VALU/latency bound (SURVEY 8d); fp64 fraction below"},
+                         "note": "path is fp64-VALU/latency bound (SURVEY 8d): the binding resource is in fp64_valu",
+                         "fp64_valu": {"bound": "fp64-valu", "achieved": round(fl / (kms * 1e-3) / 1e12, 4),
+                                       "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": fl / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
             "fp64": {"achieved_tflops": round(fl / (kms * 1e-3) / 1e12, 4),
                      "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                      "frac": fl / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
@@ -246,6 +332,22 @@ def main():
     if not args.no_sharded:
         from radex_emcee_amd.sampler import DeviceEnsembleSampler, State
         sharded = {}
+
+        def max_over_ranks(d):
+            if not use_dist:
+                return d
+            tm = torch.tensor([d], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            return float(tm.item())
+
+        def timed_run(smp, walkers, nst):
+            state = smp.run_mcmc(walkers, 1, store=False)                   # initial log-probabilities + 1 step
+            barrier()
+            ts = time.perf_counter()
+            smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
+            barrier()
+            return time.perf_counter() - ts
+
         for name, ndim, nwk, nst in (("config4", 8, 2048, 12), ("config5", 4, 65536, 6)):
             if name == "config4":
                 c = workloads.config4(nwk)
@@ -256,29 +358,60 @@ def main():
             else:
                 c = workloads.config2(nwk, seed=5678)
                 ens_src = None
-            grp = dist.group.WORLD if use_dist else None
-            smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp)
-            state = smp.run_mcmc(c["walkers"], 1, store=False)              # initial log-probabilities + 1 step
-            barrier()
-            ts = time.perf_counter()
-            smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
-            barrier()
-            d = time.perf_counter() - ts
+            rec = {"walkers": nwk, "ndim": ndim, "steps": nst, "scaling": "strong", "n_gpus": n_confirmed,
+                   "proposals_per_half_step": nwk // 2, "proposals_per_rank": -(-(nwk // 2) // world)}
+
+            def entry(d, schedule, collective, base=None):
+                e = {"schedule": schedule, "collective": collective, "ms_per_step": round(d / nst * 1e3, 3),
+                     "walker_steps_per_s": round(nwk * nst / d, 1), "solves_per_s": round(nwk * nst * (ndim // 4) / d, 1)}
+                if base is not None:
+                    e["speedup_vs_1gpu_dataflow"] = round(base / d, 3)
+                return e
+
+            # (1) ONE GPU, the dataflow kernel: the number every multi-GPU schedule has to beat (rank 0 alone)
+            d1 = 0.0
+            if rank == 0:
+                smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src)
+                state = smp.run_mcmc(c["walkers"], 1, store=False)
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
+                torch.cuda.synchronize()
+                d1 = time.perf_counter() - ts
+                del smp
+            d1 = max_over_ranks(d1)
+            rec["one_gpu_dataflow"] = entry(d1, "dataflow: one persistent kernel on ONE GPU (rank 0 alone)", "none")
             if use_dist:
-                tm = torch.tensor([d], dtype=torch.float64, device="cpu" if share else dev)
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                d = float(tm.item())
-            sharded[name] = {"walkers": nwk, "ndim": ndim, "steps": nst, "scaling": "strong",
-                             "proposals_per_half_step": nwk // 2, "proposals_per_rank": -(-(nwk // 2) // world),
-                             "ms_per_step": round(d / nst * 1e3, 3),
-                             "walker_steps_per_s": round(nwk * nst / d, 1),
-                             "solves_per_s": round(nwk * nst * (ndim // 4) / d, 1),
-                             "schedule": "dataflow (one persistent kernel)" if grp is None else
-                                         "half-steps: propose, block evaluation per rank, all-gather, accept",
-                             "collective": "none (1 GPU)" if grp is None else
-                                           "all_gather_into_tensor of %d f64 per half-step (%s)"
-                                           % (nwk // 2, "gloo rehearsal, host copies" if share else "RCCL, device")}
-            del smp
+                grp = dist.group.WORLD
+                # (2) the same ensemble across the ranks, dataflow with peer writes (falls back by itself)
+                smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp)
+                d2 = max_over_ranks(timed_run(smp, c["walkers"], nst))
+                used = smp.last_schedule
+                rec["multi_gpu_dataflow"] = entry(
+                    d2, "dataflow-peer: one persistent kernel per rank, every result published into all replicas "
+                        "(IPC-mapped fine-grained memory, system-scope stores over xGMI)" if used == "dataflow-peer"
+                    else "peer replicas unavailable (%s): half-steps + all_gather" % smp.peer_state,
+                    "none on the data path; two host barriers per run_mcmc call" if used == "dataflow-peer"
+                    else "all_gather_into_tensor per half-step", d1)
+                rec["multi_gpu_dataflow"]["ranks_share_one_gpu"] = bool(share)
+                del smp
+                # (3) north_star's literal form: block evaluation per rank + ONE all_gather of log-probabilities per half-step
+                smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp, schedule="halfsteps")
+                d3 = max_over_ranks(timed_run(smp, c["walkers"], nst))
+                rec["multi_gpu_halfsteps_allgather"] = entry(
+                    d3, "half-steps: propose, block evaluation per rank, all-gather, accept",
+                    "all_gather_into_tensor of %d f64 per half-step (%s)"
+                    % (nwk // 2, "gloo rehearsal, host copies" if share else "RCCL, device"), d1)
+                del smp
+                best = rec["multi_gpu_dataflow"] if d2 <= d3 else rec["multi_gpu_halfsteps_allgather"]
+            else:
+                best = rec["one_gpu_dataflow"]
+            # the line of this shape: the best schedule at this N, next to the one-GPU dataflow number
+            rec.update({"ms_per_step": best["ms_per_step"], "walker_steps_per_s": best["walker_steps_per_s"],
+                        "solves_per_s": best["solves_per_s"], "schedule": best["schedule"],
+                        "collective": best["collective"],
+                        "speedup_vs_1gpu_dataflow": best.get("speedup_vs_1gpu_dataflow", 1.0)})
+            sharded[name] = rec
         if not args.no_config3:
             # BASELINE configs[2] across GPUs: independent ensembles need no exchange at all -- rank r advances
             # its 16 / N sources (1024 walkers each) with the dataflow sampler; replicas, no collective
@@ -390,14 +523,46 @@ def main():
             from radex_emcee_amd.sampler import DeviceEnsembleSampler, EnsembleSampler, State
             rs = np.random.RandomState(99)
             p0 = cfg["truth"] + 1e-3 * rs.randn(nw, 4)
+            def stats_fields(stt, nst_, ms_step):
+                tasks, solved = max(1, stt["tasks"]), max(1, stt["solved"])
+                task_us = stt["busy_ticks"] / tasks / 100.0               # 100 MHz wall clock
+                floor_ms = 2.0 * task_us * 1e-3                            # a walker's own chain: two dependent tasks per step
+                return {"tasks": stt["tasks"], "proposals_outside_the_prior": round(1.0 - stt["solved"] / tasks, 4),
+                        "niter_mean": round(stt["niter_sum"] / solved, 2),
+                        "maxiter_fraction": round(stt["maxiter_solves"] / solved, 5),
+                        "mean_task_us": round(task_us, 2), "mean_wait_for_inputs_us": round(stt["wait_ticks"] / tasks / 100.0, 2),
+                        "dependency_floor_ms_per_step": round(floor_ms, 4),
+                        "fraction_of_dependency_floor": round(floor_ms / ms_step, 4)}
+
             dsm = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)       # schedule="dataflow"
             sd = dsm.run_mcmc(p0, 20, store=False)                       # a short burn-in
             torch.cuda.synchronize()
             nst = 100
+            eng.sampler_stats(True)
             ts = time.perf_counter()
             sd = dsm.run_mcmc(State(sd.coords, sd.log_prob), nst, store=False)
             torch.cuda.synchronize()
             tsd = time.perf_counter() - ts
+            stats_ball = stats_fields(eng.sampler_stats(False), nst, tsd / nst * 1e3)
+            # SURVEY 8(d) config 2 itself: the 1024 PRIOR-BOX walkers of the headline batch as the ensemble (half-step
+            # batch N = 512), same schedule, 20 steps of burn-in, then 120 timed steps with the kernel's own counters
+            dsp = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)
+            sp = dsp.run_mcmc(cfg["walkers"], 20, store=False)
+            torch.cuda.synchronize()
+            nsp = 120
+            eng.sampler_stats(True)
+            ts = time.perf_counter()
+            dsp.run_mcmc(State(sp.coords, sp.log_prob), nsp, store=False)
+            torch.cuda.synchronize()
+            tsp = time.perf_counter() - ts
+            out["sampler_config2_prior_box"] = dict(
+                {"workload": "BASELINE configs[1] as SURVEY 8(d) states it for the sampler: the %d prior-box walkers of the "
+                             "headline batch as ONE ensemble, half-step batch %d, dataflow schedule" % (nw, nw // 2),
+                 "burn_in_steps": 20, "steps": nsp, "ms_per_step": round(tsp / nsp * 1e3, 4),
+                 "walker_steps_per_s": round(nw * nsp / tsp, 1), "unit": "walker-steps/s = lnlike evaluations/s",
+                 "acceptance": round(float(dsp.acceptance_fraction.mean()), 3)},
+                **stats_fields(eng.sampler_stats(False), nsp, tsp / nsp * 1e3))
+            del dsp
             # the same 100 steps again under the half-step schedule (identical proposals), then once more with
             # HIP events around every solve launch: the mean kernel time of THIS chain's half-steps (a
             # half-step lasts as long as its slowest proposal, which varies from one half-step to the next)
@@ -420,6 +585,9 @@ def main():
                               "schedule": "dataflow: ONE persistent kernel, every proposal starts when the two "
                                           "walkers it reads are final (rx_sampler_run_async_device)",
                               "acceptance": round(float(dsm.acceptance_fraction.mean()), 3),
+                              "workload": "walkers started in the reference's ball around the truth (emcee_radex.py:477); "
+                                          "the prior-box ensemble of SURVEY 8(d) is sampler_config2_prior_box",
+                              "kernel_counters": stats_ball,
                               "half_step_schedule": {
                                   "walker_steps_per_s": round(nw * nst / tsh, 1), "ms_per_step": round(tsh / nst * 1e3, 4),
                                   "half_step_kernel_ms": round(hms, 4),
@@ -439,8 +607,12 @@ def main():
                                               "ms_per_step": round(tsd / 20 * 1e3, 3),
                                               "note": "EnsembleSampler on the host (numpy) + rx_lnprob_batch; "
                                                       "PCIe inclusive; the checker of the device sampler"}
+        if world == 1 and not args.no_sampler:
+            out["config0"] = config0_device(local)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, truth_flux)
+            if not args.no_sampler:
+                out["cpu_baseline"].update(config0_cpu(out["cpu_baseline"]["cores"]))
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

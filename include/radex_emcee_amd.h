@@ -34,11 +34,13 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 2
+#define RX_ABI_VERSION 3
 #define RX_MAX_SOURCES 64      /* sources resident in one handle (config 3: 16) */
 #define RX_MAX_NJ      32      /* observed lines per source                     */
 #define RX_MAX_LEVELS  64      /* one level per lane of a 64-wide wavefront     */
 #define RX_MAX_LINES   64
+#define RX_MAX_RANKS    8      /* GPUs of one node that one sampled ensemble may span  */
+#define RX_IPC_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t)                            */
 
 /* per-walker status (int32), mirrors the reference's error behaviour:
  *   OK       converged (Fortran conv flag or the python delta-pop test)
@@ -56,7 +58,9 @@ enum {
     RX_E_UNSUPP   = -3,   /* molecule outside the kernel's limits           */
     RX_E_NODEVICE = -4,   /* no usable HIP device                           */
     RX_E_HIP      = -5,   /* HIP runtime error                              */
-    RX_E_STATE    = -6    /* source not set, etc.                           */
+    RX_E_STATE    = -6,   /* source not set, etc.                           */
+    RX_E_TIMEOUT  = -7    /* dataflow sampler: a task gave up waiting for its inputs; the chain of that run
+                             is incomplete (rx_sampler_wait)                 */
 };
 
 typedef struct rx_handle rx_handle;
@@ -170,17 +174,65 @@ int rx_set_waves_per_simd(rx_handle *h, int waves);
  * the two walkers it reads are final (per-walker version counters in HBM) instead of waiting for the
  * whole previous half-step: a proposal that runs into maxiter delays only the tasks that depend on
  * its walker.  Asynchronous on `stream`; rx_sampler_wait synchronises the stream and reports
- * RX_E_HIP if a task gave up waiting (2 s wall clock -- the grid always drains).                */
+ * RX_E_TIMEOUT if a task gave up waiting (2 s wall clock -- the grid always drains).  The abort word is
+ * sticky per handle: once raised it ends every later run of the handle at its first wait until
+ * rx_sampler_wait has reported it (so a run enqueued before the wait cannot hide it); keep ONE async run
+ * outstanding per handle when the result of each matters on its own.                          */
 int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp, double a,
                                 uint64_t seed, int64_t step0, int nsteps,
                                 const int32_t *d_ens_src, double *d_coords, double *d_lnp,
                                 int32_t *d_naccept, double *d_chain, double *d_chain_lnp,
                                 void *stream);
-int rx_sampler_wait(rx_handle *h, void *stream);   /* after EVERY async run: a later run resets the flag */
+int rx_sampler_wait(rx_handle *h, void *stream);   /* reports (and lowers) the sticky abort word */
 /* Longest time a task of the dataflow sampler polls for its inputs before it raises the abort flag
  * (default 2000 ms; real waits are milliseconds).  0 makes every wait that is not satisfied at once
  * give up: the safety path can be exercised on purpose (tests).                                  */
 int rx_set_sampler_timeout_ms(rx_handle *h, double ms);
+
+/* The dataflow sampler across the GPUs of one node (one process per GPU) -- the device-side form of the
+ * reference's only parallelism, Pool(...).map(lnprob, walkers) (emcee/emcee_radex.py:480-488), and of
+ * SURVEY.md 8(e)'s "each GPU writes its slice to all peers": the tasks of every half-step are dealt out in
+ * contiguous blocks of ceil(nq / nranks) proposals, one block per rank; EVERY rank keeps a full replica of the
+ * sampler's shared state (per-walker version counters, positions by version, log-probabilities, acceptance
+ * counts) in one block of fine-grained device memory; a task polls and reads its own rank's replica only and
+ * publishes its result into ALL replicas with system-scope stores over xGMI (positions and log-probability
+ * first, one release fence, then the version).  No collective, no half-step barrier, no host in the loop: the
+ * chain is bit-identical to the one-GPU run.  Per run_mcmc call the host needs two barriers of its own (any
+ * transport): after rx_sampler_peer_begin on every rank (no peer may write into a replica that is still being
+ * seeded) and after rx_sampler_wait on every rank (a replica is complete only when every peer has finished).
+ *   rx_sampler_peer_setup    allocates this rank's replica for (nens, nwalkers, ncomp) and exports it:
+ *                            ipc_handle_out[RX_IPC_HANDLE_BYTES] (hipIpcGetMemHandle), may be NULL
+ *   rx_sampler_peer_base     the replica as a device pointer (peers inside ONE process: two handles, tests)
+ *   rx_sampler_peer_connect  ipc_handles: [nranks][RX_IPC_HANDLE_BYTES], every rank's handle in rank order
+ *                            (own entry ignored), or bases: [nranks] device pointers valid in this process
+ *   rx_sampler_peer_begin    seeds the replica from d_coords / d_lnp / d_naccept (may be NULL = zeros);
+ *                            returns when it IS seeded (stream synchronised)        ... barrier ...
+ *   rx_sampler_peer_run      this rank's tasks of nsteps steps as ONE persistent kernel, asynchronous; d_chain /
+ *                            d_chain_lnp (optional) receive the rows of the walkers THIS rank updated (zero them
+ *                            first and sum over ranks);  rx_sampler_wait            ... barrier ...
+ *   rx_sampler_peer_finish   final state -> d_coords / d_lnp / d_naccept; RX_E_TIMEOUT if a task on ANY rank
+ *                            gave up waiting (every rank then reports it)
+ *   rx_set_sampler_grid_limit  at most `blocks` workgroups per dataflow launch (0 = the whole GPU): ranks that
+ *                            SHARE one GPU (rehearsals) must all be resident at once                        */
+int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwalkers, int ncomp,
+                          void *ipc_handle_out);
+void *rx_sampler_peer_base(rx_handle *h);
+int rx_sampler_peer_connect(rx_handle *h, const void *ipc_handles, void *const *bases);
+int rx_sampler_peer_begin(rx_handle *h, const double *d_coords, const double *d_lnp,
+                          const int32_t *d_naccept, void *stream);
+int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, int nsteps,
+                        const int32_t *d_ens_src, double *d_chain, double *d_chain_lnp, void *stream);
+int rx_sampler_peer_finish(rx_handle *h, double *d_coords, double *d_lnp, int32_t *d_naccept,
+                           void *stream);
+int rx_sampler_peer_close(rx_handle *h);
+int rx_set_sampler_grid_limit(rx_handle *h, int blocks);
+/* Counters of the dataflow sampler's launches (benchmarks; off by default): waits for the handle's work,
+ * copies the counters accumulated since the last call into out6 (may be NULL), zeroes them and switches the
+ * counting on (enable = 1) or off for the launches that follow.  out6: [0] tasks, [1] tasks whose proposal
+ * reached the solver (lnprior finite), [2] RADEX iterations summed over them, [3] solves that stopped at
+ * maxiter, [4] 100 MHz wall-clock ticks summed over the tasks between "inputs final" and "result published",
+ * [5] ticks summed over the tasks between "dequeued" and "inputs final" (polling).                     */
+int rx_sampler_stats(rx_handle *h, int enable, uint64_t *out6);
 int rx_stretch_propose_device(rx_handle *h, int nens, int nwalkers, int ndim, double a,
                               uint64_t seed, int64_t step, int split,
                               const int32_t *d_ens_src, const double *d_coords, double *d_q,

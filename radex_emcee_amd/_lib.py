@@ -26,8 +26,13 @@ EXPORTS = [
     "rx_kernel_name", "rx_set_issue_order", "rx_stretch_propose_device", "rx_stretch_accept_device",
     "rx_sampler_run_device", "rx_set_source_prior", "rx_sampler_run_async_device", "rx_sampler_wait",
     "rx_set_sampler_timeout_ms", "rx_set_waves_per_simd",
+    "rx_sampler_peer_setup", "rx_sampler_peer_base", "rx_sampler_peer_connect", "rx_sampler_peer_begin",
+    "rx_sampler_peer_run", "rx_sampler_peer_finish", "rx_sampler_peer_close", "rx_set_sampler_grid_limit",
+    "rx_sampler_stats",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
+RX_MAX_RANKS = 8
+RX_IPC_HANDLE_BYTES = 64
 
 
 class EngineLibraryMissing(ImportError):
@@ -118,6 +123,16 @@ def load():
                                               vp, vp, vp, vp, vp, vp, vp]
     L.rx_sampler_wait.argtypes = [vp, vp]
     L.rx_set_sampler_timeout_ms.argtypes = [vp, C.c_double]
+    L.rx_sampler_peer_setup.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.rx_sampler_peer_base.argtypes = [vp]
+    L.rx_sampler_peer_base.restype = vp
+    L.rx_sampler_peer_connect.argtypes = [vp, vp, vp]
+    L.rx_sampler_peer_begin.argtypes = [vp, vp, vp, vp, vp]
+    L.rx_sampler_peer_run.argtypes = [vp, C.c_double, u64, i64, C.c_int, vp, vp, vp, vp]
+    L.rx_sampler_peer_finish.argtypes = [vp, vp, vp, vp, vp]
+    L.rx_sampler_peer_close.argtypes = [vp]
+    L.rx_set_sampler_grid_limit.argtypes = [vp, C.c_int]
+    L.rx_sampler_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
     L.rx_time_lnprob_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
     if L.rx_abi_version() != ABI_VERSION:
         raise EngineLibraryMissing("%s has ABI version %d, this package needs %d: rebuild it"

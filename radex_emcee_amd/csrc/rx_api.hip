@@ -209,6 +209,21 @@ struct rx_handle {
     uint32_t *d_abort = nullptr;
     uint32_t *h_abort = nullptr;     // pinned mirror, filled by an async copy behind every async run
     long long sampler_timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock: far beyond any real wait
+    int sampler_grid_limit = 0;      // > 0: at most this many workgroups per dataflow launch (ranks sharing one GPU)
+    unsigned long long *d_stats = nullptr;   // [8] counters of the dataflow launches since the last rx_sampler_stats
+    int stats_on = 0;
+    // multi-GPU dataflow sampler (rx_sampler_peer_*): this rank's replica block and the peers' blocks as mapped here
+    struct Peer {
+        int nranks = 0, rank = 0, nens = 0, nwalkers = 0, ncomp = 0, nsteps_run = 0;
+        size_t N = 0, bytes = 0;
+        char *own = nullptr;
+        char *base[RX_MAX_RANKS] = {};
+        bool opened[RX_MAX_RANKS] = {};          // mapped with hipIpcOpenMemHandle (to be closed)
+        char **d_bases = nullptr;                // device copy of base[]
+        unsigned long long off_version = 0, off_done = 0, off_abort = 0, off_lnp = 0, off_nacc = 0, off_hist = 0;
+        bool connected = false, begun = false;
+        int memkind = 0;                         // 1 fine-grained, 2 uncached, 3 plain hipMalloc
+    } peer;
     unsigned int *d_order_cnt = nullptr;
     int force_occ = 0;               // 0: choose by batch size; 1 / 2: wavefronts per SIMD (rx_set_waves_per_simd)
     int issue_order = 1;             // hand large batches out hottest first (rx_set_issue_order; RX_NO_ORDER=1 at rx_create: off)
@@ -562,6 +577,7 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
 void rx_destroy(rx_handle *h)
 {
     if (!h) return;
+    (void)hipSetDevice(h->device);                                           // (a multi-GPU process may be on another one)
     if (h->in_flight && h->ev_done) (void)hipEventSynchronize(h->ev_done);   // nothing of this handle still runs
     h->in_flight = false;
     if (h->d_blob) (void)hipFree(h->d_blob);
@@ -580,6 +596,8 @@ void rx_destroy(rx_handle *h)
     h->w_q.release(); h->w_factor.release(); h->w_lnpq.release(); h->w_widx.release();
     h->w_qsrc.release(); h->w_qstatus.release(); h->w_qniter.release(); h->w_version.release(); h->w_hist.release();
     if (h->d_abort) (void)hipFree(h->d_abort);
+    if (h->d_stats) (void)hipFree(h->d_stats);
+    (void)rx_sampler_peer_close(h);
     if (h->h_abort) (void)hipHostFree(h->h_abort);
     delete h;
 }
@@ -851,10 +869,13 @@ int rx_lubksb_pivots_batch(rx_handle *h, int N, int n, const double *A, double *
     HIPCHK(h, h->s_params.reserve((size_t)N * n * n));
     HIPCHK(h, h->s_lnp.reserve((size_t)N * n));
     if (pivrow) HIPCHK(h, h->s_status.reserve((size_t)N * n));
-    HIPCHK(h, hipMemcpy(h->s_params.p, A, (size_t)N * n * n * sizeof(double), hipMemcpyHostToDevice));
+    // (the staging buffers belong to the handle: behind whatever it launched last, like every entry point)
+    { int rc = order_after_last(h, nullptr); if (rc) return rc; }
+    HIPCHK(h, hipMemcpyAsync(h->s_params.p, A, (size_t)N * n * n * sizeof(double), hipMemcpyHostToDevice, nullptr));
     hipLaunchKernelGGL(lukernel_for(h->NL), dim3(N), dim3(64), 0, nullptr, h->s_params.p, h->s_lnp.p,
                        pivrow ? h->s_status.p : nullptr, n, N);
     HIPCHK(h, hipGetLastError());
+    { int rc = mark_launched(h, nullptr); if (rc) return rc; }
     HIPCHK(h, hipMemcpy(x, h->s_lnp.p, (size_t)N * n * sizeof(double), hipMemcpyDeviceToHost));
     if (pivrow) HIPCHK(h, hipMemcpy(pivrow, h->s_status.p, (size_t)N * n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
@@ -867,9 +888,11 @@ int rx_escprob_batch(rx_handle *h, int method, int N, const double *tau, double 
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, h->s_params.reserve((size_t)N));
     HIPCHK(h, h->s_lnp.reserve((size_t)N));
-    HIPCHK(h, hipMemcpy(h->s_params.p, tau, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    { int rc = order_after_last(h, nullptr); if (rc) return rc; }
+    HIPCHK(h, hipMemcpyAsync(h->s_params.p, tau, (size_t)N * sizeof(double), hipMemcpyHostToDevice, nullptr));
     hipLaunchKernelGGL(rxk::rx_escprob_kernel, dim3((N + 63) / 64), dim3(64), 0, nullptr, h->s_params.p, h->s_lnp.p, method, N);
     HIPCHK(h, hipGetLastError());
+    { int rc = mark_launched(h, nullptr); if (rc) return rc; }
     HIPCHK(h, hipMemcpy(beta, h->s_lnp.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1013,7 +1036,7 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     constexpr int RING = 12;                         // versions of the positions kept readable (see the kernel)
     HIPCHK(h, h->w_version.reserve(N + RING));
     HIPCHK(h, h->w_hist.reserve((size_t)RING * N * ndim));
-    if (!h->d_abort) HIPCHK(h, hipMalloc(&h->d_abort, sizeof(uint32_t)));
+    if (!h->d_abort) { HIPCHK(h, hipMalloc(&h->d_abort, sizeof(uint32_t))); HIPCHK(h, hipMemset(h->d_abort, 0, sizeof(uint32_t))); }
     if (!h->h_abort) { HIPCHK(h, hipHostMalloc(&h->h_abort, sizeof(uint32_t))); *h->h_abort = 0; }
     // few tasks per half-step: one wavefront per SIMD (lowest latency per task), the whole chip so that
     // wavefronts can run ahead of a slow task; many: two per SIMD (throughput)
@@ -1033,8 +1056,10 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     A.hist = h->w_hist.p; A.done = h->w_version.p + N; A.ring = RING;
     A.chain = d_chain; A.chain_lnp = d_chain_lnp;
     A.timeout_ticks = h->sampler_timeout_ticks;
+    A.stats = h->stats_on ? h->d_stats : nullptr;
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
-    HIPCHK(h, hipMemsetAsync(h->d_abort, 0, sizeof(uint32_t), st));
+    // (the abort word is STICKY: raised by a run, it stays up -- and ends every later run at its first wait --
+    // until rx_sampler_wait has reported it; a second run enqueued before the wait cannot lose it)
     HIPCHK(h, hipMemsetAsync(h->w_version.p, 0, (N + RING) * sizeof(uint32_t), st));
     HIPCHK(h, hipMemcpyAsync(h->w_hist.p, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));   // version 0
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, A);
@@ -1043,6 +1068,222 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
                              hipMemcpyDeviceToDevice, st));                                                  // version nsteps
     HIPCHK(h, hipMemcpyAsync(h->h_abort, h->d_abort, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     return mark_launched(h, st);
+}
+
+// ---- the dataflow sampler across GPUs: replicas written by peers -------------
+static constexpr int PEER_RING = 12;
+
+static int peer_launch_shape(rx_handle *h, size_t tasks_per_half_step, size_t total_tasks, int *occ_out, long *blocks_out)
+{
+    int occ = (tasks_per_half_step > (size_t)3 * h->num_cu * RXK_WAVES_PER_BLOCK / 2 && h->blocks_per_cu2 >= 2) ? 2 : 1;
+    if (h->force_occ == 1 || (h->force_occ == 2 && h->blocks_per_cu2 >= 2)) occ = h->force_occ;
+    long blocks = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
+    const long need = (long)((total_tasks + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK);
+    if (blocks > need) blocks = need;
+    if (h->sampler_grid_limit > 0 && blocks > h->sampler_grid_limit) blocks = h->sampler_grid_limit;
+    if (blocks < 1) blocks = 1;
+    *occ_out = occ; *blocks_out = blocks;
+    return 0;
+}
+
+int rx_set_sampler_grid_limit(rx_handle *h, int blocks)
+{
+    if (!h || blocks < 0) return RX_E_ARG;
+    h->sampler_grid_limit = blocks;
+    return 0;
+}
+
+int rx_sampler_peer_close(rx_handle *h)
+{
+    if (!h) return RX_E_ARG;
+    rx_handle::Peer &P = h->peer;
+    if (!P.own && !P.d_bases) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->in_flight && h->ev_done) { (void)hipEventSynchronize(h->ev_done); h->in_flight = false; }
+    for (int r = 0; r < RX_MAX_RANKS; ++r)
+        if (P.opened[r] && P.base[r]) (void)hipIpcCloseMemHandle(P.base[r]);
+    if (P.d_bases) (void)hipFree(P.d_bases);
+    if (P.own) (void)hipFree(P.own);
+    P = rx_handle::Peer();
+    return 0;
+}
+
+int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwalkers, int ncomp, void *ipc_handle_out)
+{
+    if (!h || nranks < 1 || nranks > RX_MAX_RANKS || rank < 0 || rank >= nranks) return RX_E_ARG;
+    rxs::StretchArgs probe;
+    { int rc = stretch_args(h, probe, nens, nwalkers, 4 * ncomp, 2.0, 0, 0, 0); if (rc) return rc; }
+    if (ncomp != 1 && ncomp != 2) { h->err = "ncomp must be 1 or 2"; return RX_E_ARG; }
+    (void)rx_sampler_peer_close(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    rx_handle::Peer &P = h->peer;
+    P.nranks = nranks; P.rank = rank; P.nens = nens; P.nwalkers = nwalkers; P.ncomp = ncomp;
+    P.N = (size_t)nens * nwalkers;
+    const size_t N = P.N, ndim = 4 * (size_t)ncomp;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t off = 0;
+    P.off_version = off; off = up(off + N * sizeof(uint32_t));
+    P.off_done = off;    off = up(off + PEER_RING * sizeof(uint32_t));
+    P.off_abort = off;   off = up(off + sizeof(uint32_t));
+    P.off_nacc = off;    off = up(off + N * sizeof(int32_t));
+    P.off_lnp = off;     off = up(off + N * sizeof(double));
+    P.off_hist = off;    off = up(off + (size_t)PEER_RING * N * ndim * sizeof(double));
+    P.bytes = off;
+    // fine-grained device memory: writes of a peer GPU become visible to this GPU's system-scope loads while
+    // both kernels run (coarse-grained allocations are only coherent at kernel boundaries)
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, P.bytes, hipDeviceMallocFinegrained);
+    P.memkind = 1;
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, P.bytes, hipDeviceMallocUncached); P.memkind = 2; }
+    if (e != hipSuccess) { (void)hipGetLastError(); P = rx_handle::Peer(); return hip_fail(h, e, "rx_sampler_peer_setup: hipExtMallocWithFlags(fine-grained)"); }
+    P.own = (char *)p;
+    HIPCHK(h, hipMemset(P.own, 0, P.bytes));
+    if (ipc_handle_out) {
+        hipIpcMemHandle_t ih;
+        e = hipIpcGetMemHandle(&ih, P.own);
+        if (e != hipSuccess) { (void)hipGetLastError(); (void)rx_sampler_peer_close(h); return hip_fail(h, e, "rx_sampler_peer_setup: hipIpcGetMemHandle"); }
+        static_assert(sizeof ih == RX_IPC_HANDLE_BYTES, "ipc handle size");
+        memcpy(ipc_handle_out, &ih, sizeof ih);
+    }
+    return 0;
+}
+
+void *rx_sampler_peer_base(rx_handle *h) { return h ? (void *)h->peer.own : nullptr; }
+
+int rx_sampler_peer_connect(rx_handle *h, const void *ipc_handles, void *const *bases)
+{
+    if (!h || (!ipc_handles && !bases)) return RX_E_ARG;
+    rx_handle::Peer &P = h->peer;
+    if (!P.own) { h->err = "rx_sampler_peer_connect: call rx_sampler_peer_setup first"; return RX_E_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int r = 0; r < P.nranks; ++r) {
+        if (r == P.rank) { P.base[r] = P.own; continue; }
+        if (bases) { P.base[r] = (char *)bases[r]; continue; }
+        hipIpcMemHandle_t ih;
+        memcpy(&ih, (const char *)ipc_handles + (size_t)r * RX_IPC_HANDLE_BYTES, sizeof ih);
+        void *q = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&q, ih, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); return hip_fail(h, e, "rx_sampler_peer_connect: hipIpcOpenMemHandle"); }
+        P.base[r] = (char *)q; P.opened[r] = true;
+    }
+    for (int r = 0; r < P.nranks; ++r)
+        if (!P.base[r]) { h->err = "rx_sampler_peer_connect: a peer's replica is missing"; return RX_E_ARG; }
+    if (!P.d_bases) HIPCHK(h, hipMalloc(&P.d_bases, RX_MAX_RANKS * sizeof(char *)));
+    HIPCHK(h, hipMemcpy(P.d_bases, P.base, RX_MAX_RANKS * sizeof(char *), hipMemcpyHostToDevice));
+    P.connected = true;
+    return 0;
+}
+
+int rx_sampler_peer_begin(rx_handle *h, const double *d_coords, const double *d_lnp, const int32_t *d_naccept, void *stream)
+{
+    if (!h || !d_coords || !d_lnp) return RX_E_ARG;
+    rx_handle::Peer &P = h->peer;
+    if (!P.connected) { h->err = "rx_sampler_peer_begin: not connected"; return RX_E_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = order_after_last(h, st); if (rc) return rc; }
+    const size_t N = P.N, ndim = 4 * (size_t)P.ncomp;
+    // version counters, per-step counters, abort word, acceptance counts: zero ... then the state the run starts from
+    HIPCHK(h, hipMemsetAsync(P.own, 0, (size_t)P.off_lnp, st));
+    if (d_naccept) HIPCHK(h, hipMemcpyAsync(P.own + P.off_nacc, d_naccept, N * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(P.own + P.off_lnp, d_lnp, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(P.own + P.off_hist, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));   // version 0
+    HIPCHK(h, hipStreamSynchronize(st));          // the caller's barrier across ranks follows: the replica must BE ready
+    P.begun = true;
+    return 0;
+}
+
+int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, int nsteps, const int32_t *d_ens_src,
+                        double *d_chain, double *d_chain_lnp, void *stream)
+{
+    if (!h || nsteps < 0) return RX_E_ARG;
+    rx_handle::Peer &P = h->peer;
+    if (!P.connected || !P.begun) { h->err = "rx_sampler_peer_run: rx_sampler_peer_begin (and the barrier behind it) first"; return RX_E_STATE; }
+    const int ndim = 4 * P.ncomp;
+    rxs::AsyncArgs A;
+    memset(&A, 0, sizeof A);
+    { int rc = stretch_args(h, A.s, P.nens, P.nwalkers, ndim, a, seed, step0, 0); if (rc) return rc; }
+    if (step0 + nsteps > 0xffffffffLL) { h->err = "stretch move: step counter exceeds 32 bits"; return RX_E_ARG; }
+    { int rc = device_batch_ncomp(h, (int)P.N, P.ncomp, d_ens_src); if (rc) return rc; }
+    const size_t N = P.N, nq = N / 2;
+    // contiguous blocks of ceil(nq / nranks) proposals of every half-step, one per rank (sampler.block_partition)
+    const size_t per = (nq + P.nranks - 1) / P.nranks;
+    const size_t lo = std::min((size_t)P.rank * per, nq), hi = std::min(lo + per, nq);
+    if ((double)nsteps * 2.0 * (double)(hi - lo) >= 4294967295.0) { h->err = "stretch move: more than 2^32 tasks in one launch"; return RX_E_ARG; }
+    P.begun = false;
+    P.nsteps_run = nsteps;
+    if (nsteps == 0) return 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = order_after_last(h, st); if (rc) return rc; }
+    if (!h->h_abort) { HIPCHK(h, hipHostMalloc(&h->h_abort, sizeof(uint32_t))); *h->h_abort = 0; }
+    int occ; long blocks;
+    peer_launch_shape(h, hi - lo, 2 * (hi - lo) * (size_t)nsteps, &occ, &blocks);
+    sampler_kernel_fn k = sampler_kernel_for(h->NL, occ, h->mol.nlev == h->NL);
+    if (!k) { h->err = "this build has no dataflow sampler kernel"; return RX_E_UNSUPP; }
+    fill_args(h, A.k, (int)N, P.ncomp, RXK_MODE_LNPROB);
+    A.s.ens_src = d_ens_src;
+    A.s.coords = nullptr;
+    A.s.lnp = (double *)(P.own + P.off_lnp);
+    A.s.naccept = (int32_t *)(P.own + P.off_nacc);
+    A.nsteps = nsteps; A.ncomp = P.ncomp;
+    A.version = (uint32_t *)(P.own + P.off_version);
+    A.done = (uint32_t *)(P.own + P.off_done);
+    A.abort_flag = (uint32_t *)(P.own + P.off_abort);
+    A.hist = (double *)(P.own + P.off_hist);
+    A.ring = PEER_RING;
+    A.chain = d_chain; A.chain_lnp = d_chain_lnp;
+    A.timeout_ticks = h->sampler_timeout_ticks;
+    A.stats = h->stats_on ? h->d_stats : nullptr;
+    // (nranks = 1 runs the very same kernel in its one-GPU form on the replica block)
+    A.nranks = P.nranks; A.rank = P.rank; A.t_lo = (uint32_t)lo; A.t_n = (uint32_t)(hi - lo);
+    A.peers = P.d_bases;
+    A.off_version = P.off_version; A.off_done = P.off_done; A.off_abort = P.off_abort;
+    A.off_lnp = P.off_lnp; A.off_nacc = P.off_nacc; A.off_hist = P.off_hist;
+    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, A);
+    HIPCHK(h, hipGetLastError());
+    return mark_launched(h, st);
+}
+
+int rx_sampler_peer_finish(rx_handle *h, double *d_coords, double *d_lnp, int32_t *d_naccept, void *stream)
+{
+    if (!h || !d_coords || !d_lnp) return RX_E_ARG;
+    rx_handle::Peer &P = h->peer;
+    if (!P.connected) { h->err = "rx_sampler_peer_finish: not connected"; return RX_E_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = order_after_last(h, st); if (rc) return rc; }
+    const size_t N = P.N, ndim = 4 * (size_t)P.ncomp;
+    if (!h->h_abort) { HIPCHK(h, hipHostMalloc(&h->h_abort, sizeof(uint32_t))); *h->h_abort = 0; }
+    HIPCHK(h, hipMemcpyAsync(h->h_abort, P.own + P.off_abort, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(d_coords, P.own + P.off_hist + (size_t)(P.nsteps_run % PEER_RING) * N * ndim * sizeof(double),
+                             N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));          // version nsteps
+    HIPCHK(h, hipMemcpyAsync(d_lnp, P.own + P.off_lnp, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (d_naccept) HIPCHK(h, hipMemcpyAsync(d_naccept, P.own + P.off_nacc, N * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (*h->h_abort) {
+        *h->h_abort = 0;
+        h->err = "dataflow sampler (multi-GPU): a task on some rank waited longer than the timeout for its inputs (chain incomplete)";
+        return RX_E_TIMEOUT;
+    }
+    return 0;
+}
+
+int rx_sampler_stats(rx_handle *h, int enable, uint64_t *out6)
+{
+    if (!h) return RX_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->d_stats) { HIPCHK(h, hipMalloc(&h->d_stats, 8 * sizeof(unsigned long long))); HIPCHK(h, hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long))); }
+    if (h->in_flight) { HIPCHK(h, hipEventSynchronize(h->ev_done)); h->in_flight = false; }
+    if (out6) {
+        unsigned long long v[8];
+        HIPCHK(h, hipMemcpy(v, h->d_stats, sizeof v, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 6; ++i) out6[i] = v[i];
+    }
+    HIPCHK(h, hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long)));
+    h->stats_on = enable ? 1 : 0;
+    return 0;
 }
 
 int rx_set_sampler_timeout_ms(rx_handle *h, double ms)
@@ -1059,8 +1300,9 @@ int rx_sampler_wait(rx_handle *h, void *stream)
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     if (h->h_abort && *h->h_abort) {
         *h->h_abort = 0;
+        if (h->d_abort) HIPCHK(h, hipMemset(h->d_abort, 0, sizeof(uint32_t)));      // reported: lowered again
         h->err = "dataflow sampler: a task waited longer than the timeout for its inputs (chain incomplete)";
-        return RX_E_HIP;
+        return RX_E_TIMEOUT;
     }
     return 0;
 }

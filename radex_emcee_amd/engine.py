@@ -18,7 +18,14 @@ METHODS = {"sphere": 1, "lvg": 2, "slab": 3}      # core.py:690-700
 
 
 class EngineError(RuntimeError):
-    pass
+    """A C-ABI call failed; `rc` is its RX_E_* return code."""
+
+    def __init__(self, msg, rc=None):
+        super().__init__(msg)
+        self.rc = rc
+
+
+RX_E_TIMEOUT = -7        # include/radex_emcee_amd.h: a task of the dataflow sampler gave up waiting
 
 
 def _dp(a):
@@ -70,7 +77,7 @@ class Engine:
 
     def _chk(self, rc, what):
         if rc != 0:
-            raise EngineError("%s failed (rc=%d): %s" % (what, rc, self._L.rx_last_error(self._h).decode()))
+            raise EngineError("%s failed (rc=%d): %s" % (what, rc, self._L.rx_last_error(self._h).decode()), rc)
 
     @property
     def kernel_name(self) -> str:
@@ -259,6 +266,58 @@ class Engine:
         import torch
         dev = torch.device("cuda", self.device) if device is None else device
         self._chk(self._L.rx_sampler_wait(self._h, self._stream(dev, stream)), "rx_sampler_wait")
+
+    # -- the dataflow sampler across GPUs: replicas written by peers (rx_sampler_peer_*) -----------------
+    def sampler_peer_setup(self, nranks, rank, nens, nwalkers, ncomp, export=True):
+        """Allocates this rank's replica; returns its IPC handle (64 bytes) or None with export=False."""
+        buf = C.create_string_buffer(_lib.RX_IPC_HANDLE_BYTES) if export else None
+        self._chk(self._L.rx_sampler_peer_setup(self._h, int(nranks), int(rank), int(nens), int(nwalkers), int(ncomp),
+                                                C.cast(buf, C.c_void_p) if export else None), "rx_sampler_peer_setup")
+        return bytes(buf.raw) if export else None
+
+    def sampler_peer_base(self):
+        return self._L.rx_sampler_peer_base(self._h)
+
+    def sampler_peer_connect(self, ipc_handles=None, bases=None):
+        """ipc_handles: one 64-byte handle per rank, in rank order -- or bases: device pointers (same process)."""
+        if ipc_handles is not None:
+            blob = b"".join(bytes(x) for x in ipc_handles)
+            buf = C.create_string_buffer(blob, len(blob))
+            rc = self._L.rx_sampler_peer_connect(self._h, C.cast(buf, C.c_void_p), None)
+        else:
+            arr = (C.c_void_p * len(bases))(*[C.c_void_p(int(b)) for b in bases])
+            rc = self._L.rx_sampler_peer_connect(self._h, None, C.cast(arr, C.c_void_p))
+        self._chk(rc, "rx_sampler_peer_connect")
+
+    def sampler_peer_begin(self, coords, lnp, naccept=None, stream=None):
+        self._chk(self._L.rx_sampler_peer_begin(self._h, coords.data_ptr(), lnp.data_ptr(),
+                                                0 if naccept is None else naccept.data_ptr(),
+                                                self._stream(coords.device, stream)), "rx_sampler_peer_begin")
+
+    def sampler_peer_run(self, a, seed, step0, nsteps, device, chain=None, chain_lnp=None, ens_src=None, stream=None):
+        p = lambda t: 0 if t is None else t.data_ptr()
+        self._chk(self._L.rx_sampler_peer_run(self._h, float(a), int(seed), int(step0), int(nsteps), p(ens_src),
+                                              p(chain), p(chain_lnp), self._stream(device, stream)), "rx_sampler_peer_run")
+
+    def sampler_peer_finish(self, coords, lnp, naccept=None, stream=None):
+        self._chk(self._L.rx_sampler_peer_finish(self._h, coords.data_ptr(), lnp.data_ptr(),
+                                                 0 if naccept is None else naccept.data_ptr(),
+                                                 self._stream(coords.device, stream)), "rx_sampler_peer_finish")
+
+    def sampler_peer_close(self):
+        self._chk(self._L.rx_sampler_peer_close(self._h), "rx_sampler_peer_close")
+
+    def set_sampler_grid_limit(self, blocks=0):
+        """At most `blocks` workgroups per dataflow launch (0: the whole GPU) -- ranks sharing one GPU."""
+        self._chk(self._L.rx_set_sampler_grid_limit(self._h, int(blocks)), "rx_set_sampler_grid_limit")
+
+    def sampler_stats(self, enable=True):
+        """Counters of the dataflow launches since the last call (rx_sampler_stats), then counting on / off."""
+        v = (C.c_uint64 * 6)()
+        self._chk(self._L.rx_sampler_stats(self._h, 1 if enable else 0, v), "rx_sampler_stats")
+        t = dict(tasks=int(v[0]), solved=int(v[1]), niter_sum=int(v[2]), maxiter_solves=int(v[3]),
+                 busy_ticks=int(v[4]), wait_ticks=int(v[5]))
+        return t
 
     def set_sampler_timeout_ms(self, ms):
         self._chk(self._L.rx_set_sampler_timeout_ms(self._h, float(ms)), "rx_set_sampler_timeout_ms")

@@ -65,7 +65,22 @@ def result_tuple(source, z, bounds, Jup, flux, eflux, popt, pcov, pmin, theta_me
     """(source, z, bounds[, T_d], (Jup, flux, eflux), (popt, pcov), pmin, theta_med, (chain, lnprob))
     -- emcee_radex.py:504-509; the 2-component script inserts T_d after bounds (:580-585)."""
     head = (source, z, bounds) + ((T_d,) if T_d is not None else ())
+    flux, eflux = _jykms(flux), _jykms(eflux)
     return head + ((Jup, flux, eflux), (popt, pcov), pmin, theta_med, (chain, lnprobability))
+
+
+def _jykms(v):
+    """The reference pickles flux / eflux as astropy Quantities in Jy km/s (get_source,
+    emcee_radex.py:229-240) and its replot reads `flux.value` (:315): wrap them when astropy can be
+    imported, so that a pickle written here opens there; plain arrays otherwise (astropy is not a
+    dependency of this package)."""
+    if hasattr(v, "unit"):
+        return v
+    try:
+        import astropy.units as u
+    except Exception:
+        return np.asarray(v)
+    return u.Quantity(np.asarray(v, dtype=float), u.Jy * u.km / u.s)
 
 
 def save_result(path, tup):

@@ -22,6 +22,11 @@ fortho = opr / (1 + opr)                 # emcee_radex.py:95-96
 
 R = None                                  # per-process engine handle, like the reference's global
 
+# Source slots of the process-wide engine: slot 0 belongs to the LIVE sampler (EnsembleSampler below keeps
+# reading it for its whole life: burn-in, reset, production); the per-walker functions with the reference's
+# signatures are pure, like the reference's, and evaluate in scratch slots of their own.
+_SLOT_SAMPLER, _SLOT_LNPROB, _SLOT_SCRATCH = 0, 62, 63        # (RX_MAX_SOURCES = 64)
+
 
 def init_radex(tbg=2.7315, molfile=None, device=0):
     """emcee_radex.py:104-117: one handle per process/GPU."""
@@ -76,8 +81,8 @@ def model_lvg(Jup, params, R=None):
     ncomp = p.size // 4
     Jup = np.asarray(np.int_(Jup))
     wide = np.tile(np.array([-np.inf, np.inf]), (4 * ncomp, 1))
-    R.set_source(R._tbg, Jup, np.zeros(len(Jup)), np.ones(len(Jup)), wide, ncomp, None, src=0)
-    flux, status, _ = R.model_flux_batch(p[None, :], src=0, return_info=True)
+    R.set_source(R._tbg, Jup, np.zeros(len(Jup)), np.ones(len(Jup)), wide, ncomp, None, src=_SLOT_SCRATCH)
+    flux, status, _ = R.model_flux_batch(p[None, :], src=_SLOT_SCRATCH, return_info=True)
     if status[0] == 2:
         raise ValueError("parameters outside RADEX's valid range (temperature/column/colliders)")
     return flux[0]
@@ -125,12 +130,9 @@ def lnlike(p, Jup, flux, eflux, R=None, sigma_floor=1e-12):
     if sigma_floor > 1e-12:                       # (the engine's own floor is the reference's default 1e-12)
         e = np.maximum(np.abs(e), sigma_floor)
     wide = np.tile(np.array([-np.inf, np.inf]), (4 * ncomp, 1))
-    R.set_source(R._tbg, Jup, np.asarray(flux, dtype=np.float64), e, wide, ncomp, None, src=0)
-    R.set_source_prior(0, False)
-    try:
-        return float(R.lnprob_batch(p[None, :])[0])
-    finally:
-        R.set_source_prior(0, True)
+    R.set_source(R._tbg, Jup, np.asarray(flux, dtype=np.float64), e, wide, ncomp, None, src=_SLOT_SCRATCH)
+    R.set_source_prior(_SLOT_SCRATCH, False)
+    return float(R.lnprob_batch(p[None, :], src_index=np.array([_SLOT_SCRATCH], dtype=np.int32))[0])
 
 
 def lnprob(p, Jup, flux, eflux, bounds=None, T_d=None):
@@ -140,8 +142,8 @@ def lnprob(p, Jup, flux, eflux, bounds=None, T_d=None):
         raise RuntimeError("call init_radex(tbg) first")
     p = np.asarray(p, dtype=np.float64)
     ncomp = p.size // 4
-    eng.set_source(eng._tbg, np.asarray(np.int_(Jup)), flux, eflux, bounds, ncomp, T_d, src=0)
-    return float(eng.lnprob_batch(p[None, :])[0])
+    eng.set_source(eng._tbg, np.asarray(np.int_(Jup)), flux, eflux, bounds, ncomp, T_d, src=_SLOT_LNPROB)
+    return float(eng.lnprob_batch(p[None, :], src_index=np.array([_SLOT_LNPROB], dtype=np.int32))[0])
 
 
 def EnsembleSampler(nwalkers, ndim, log_prob_fn, args=None, kwargs=None, pool=None, seed=0, **options):
@@ -165,6 +167,6 @@ def EnsembleSampler(nwalkers, ndim, log_prob_fn, args=None, kwargs=None, pool=No
         Jup, flux, eflux = a
         ncomp = int(ndim) // 4
         eng.set_source(eng._tbg, np.asarray(np.int_(Jup)), np.asarray(flux, dtype=np.float64),
-                       np.asarray(eflux, dtype=np.float64), kw.get("bounds"), ncomp, kw.get("T_d"), src=0)
+                       np.asarray(eflux, dtype=np.float64), kw.get("bounds"), ncomp, kw.get("T_d"), src=_SLOT_SAMPLER)
         return _s.DeviceEnsembleSampler(nwalkers, ndim, engine=eng, seed=seed, **options)
     return _s.EnsembleSampler(nwalkers, ndim, log_prob_fn, args=args, kwargs=kwargs, pool=pool, seed=seed, **options)

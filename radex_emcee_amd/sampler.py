@@ -409,12 +409,19 @@ class DeviceEnsembleSampler:
     log_prob_fn  a host function (numpy in, numpy out): CPU restatement of the same kernels (checker)
     nens      independent ensembles advancing together (BASELINE config 3: one per source);
               ens_src[nens] = source slot of each (default: slot 0 for all)
-    schedule  "dataflow" (default, one GPU): the chain as one persistent kernel whose tasks start when
+    schedule  "dataflow" (default): the chain as one persistent kernel (per GPU) whose tasks start when
               their two input walkers are final; "halfsteps": one propose / solve / accept round per half-step
-    group     torch.distributed group: each half-step's proposals are evaluated in contiguous
-              blocks, one per rank, and ONE all_gather of log-probabilities (RCCL on GPUs) precedes the
-              accept step; positions and the counter-based random stream are replicated, so the
-              proposals need no exchange and every rank accepts identically."""
+    group     torch.distributed group, one process per GPU: the proposals of every half-step are dealt out
+              in contiguous blocks, one per rank (the reference's Pool.map over walkers,
+              emcee_radex.py:480-488).  schedule="dataflow": every rank runs its block's tasks in its own
+              persistent kernel and publishes each result into the replicas of ALL ranks with peer writes
+              over xGMI (rx_sampler_peer_*: IPC-mapped fine-grained memory, no collective, no barrier per
+              half-step, no host in the loop; two host barriers per run_mcmc call); it falls back to
+              "halfsteps" -- block evaluation per rank, ONE all_gather of log-probabilities (RCCL on GPUs)
+              before the accept step, SURVEY 8e's literal form and the checker of the peer path -- when
+              the replicas cannot be shared (IPC unavailable).  Positions and the counter-based random
+              stream are replicated either way, so the proposals need no exchange and every rank accepts
+              identically.  The chain is the one-GPU chain, bit for bit, under both schedules."""
 
     def __init__(self, nwalkers, ndim, engine=None, log_prob_fn=None, nens=1, ens_src=None, a=2.0, seed=0,
                  group=None, sharded=None, schedule="dataflow"):
@@ -426,6 +433,8 @@ class DeviceEnsembleSampler:
             raise ValueError("The number of walkers must be even")
         if (engine is None) == (log_prob_fn is None):
             raise ValueError("give exactly one of engine / log_prob_fn")
+        if engine is not None and int(ndim) not in (4, 8):
+            raise ValueError("the engine evaluates 1- or 2-component models: ndim must be 4 or 8")
         self.nwalkers, self.ndim, self.nens = int(nwalkers), int(ndim), int(nens)
         self.a, self.seed = float(a), int(seed)
         self.engine = engine
@@ -465,6 +474,8 @@ class DeviceEnsembleSampler:
         if schedule not in ("dataflow", "halfsteps"):
             raise ValueError("schedule must be 'dataflow' or 'halfsteps'")
         self.schedule = schedule
+        self.peer_state = None            # None: not tried yet; True: replicas connected; str: why not (halfsteps then)
+        self.last_schedule = None         # what the last run_mcmc actually used
         self.fallback = True              # dataflow run abandoned (timeout) -> repeat it per half-step
         self.step_counter = 0
         self.time_solves = False          # benchmarks: sum the solve-kernel time of every half-step (HIP events)
@@ -483,10 +494,9 @@ class DeviceEnsembleSampler:
         return v if self.nens == 1 else v.reshape(self.nens, self.nwalkers)
 
     def _cat(self, parts, tail):
-        import torch
         if not parts:
             return np.empty((0,) + tail)
-        return torch.cat(parts).cpu().numpy()
+        return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
     def get_chain(self, flat=False, thin=1, discard=0):
         v = self._cat(self._chain, (self.N, self.ndim))[discard::thin]
@@ -538,9 +548,102 @@ class DeviceEnsembleSampler:
             self.backend.evaluate(self, X, out, src)
         return out
 
+    # --- the dataflow schedule across the ranks of the group (peer writes into IPC-mapped replicas) --------
+    def _gather_objects(self, obj):
+        out = [None] * self.world
+        if self.world == 1:
+            return [obj]
+        self._dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def _barrier(self):
+        if self.world > 1:
+            self._dist.barrier(group=self.group)
+
+    def _peer_setup(self):
+        """Allocates this rank's replica, exchanges the IPC handles, maps the peers'.  Collective: every rank
+        learns whether ALL ranks succeeded; otherwise all fall back to the half-step schedule together."""
+        import os
+        import socket
+        from .engine import EngineError
+        eng, err, handle = self.engine, None, None
+        try:
+            handle = eng.sampler_peer_setup(self.world, self.rank, self.nens, self.nwalkers, self.ndim // 4)
+        except EngineError as exc:
+            err = str(exc)
+        me = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
+              os.environ.get("CUDA_VISIBLE_DEVICES"), eng.device)
+        infos = self._gather_objects((handle, err, me))
+        bad = [i for i, (_, e, _) in enumerate(infos) if e]
+        if not bad:
+            # ranks that share one GPU (rehearsals on a one-GPU box) must all be resident at once: split the CUs
+            nshare = sum(1 for (_, _, m) in infos if m == me)
+            if nshare > 1:
+                import torch
+                ncu = torch.cuda.get_device_properties(self.coords.device).multi_processor_count
+                eng.set_sampler_grid_limit(max(1, ncu // nshare))
+            try:
+                eng.sampler_peer_connect(ipc_handles=[h for (h, _, _) in infos])
+            except EngineError as exc:
+                err = str(exc)
+            errs = self._gather_objects(err)
+            bad = [i for i, e in enumerate(errs) if e]
+            if bad:
+                err = "rank %d: %s" % (bad[0], errs[bad[0]])
+        else:
+            err = "rank %d: %s" % (bad[0], infos[bad[0]][1])
+        if bad:
+            try:
+                eng.sampler_peer_close()
+            except EngineError:
+                pass
+            self.peer_state = err
+            if self.rank == 0:
+                import warnings
+                warnings.warn("multi-GPU dataflow sampler unavailable (%s): half-steps + all_gather instead" % err)
+            return False
+        self.peer_state = True
+        return True
+
+    def _run_peer(self, nsteps, chain, chain_lnp):
+        """One run_mcmc call under the peer-write dataflow schedule.  Returns False when a task on some rank gave
+        up waiting (every rank sees it): the caller repeats the run per half-step."""
+        import torch
+        from .engine import EngineError, RX_E_TIMEOUT
+        eng, dev = self.engine, self.coords.device
+        eng.sampler_peer_begin(self.coords, self.lnp, self.naccept)
+        self._barrier()                               # every replica is seeded: peers may write into it
+        eng.sampler_peer_run(self.a, self.seed, self.step_counter, nsteps, dev, chain, chain_lnp, ens_src=self.ens_src)
+        timed_out = False
+        try:
+            eng.sampler_wait(dev)
+        except EngineError as exc:                    # (the one-GPU flag; the replicas' abort word is read by finish)
+            if exc.rc != RX_E_TIMEOUT:
+                raise
+            timed_out = True
+        self._barrier()                               # every peer has finished: this rank's replica is complete
+        try:
+            eng.sampler_peer_finish(self.coords, self.lnp, self.naccept)
+        except EngineError as exc:
+            if exc.rc != RX_E_TIMEOUT:
+                raise
+            timed_out = True
+        if timed_out:
+            return False
+        if chain is not None and self.world > 1:      # each rank wrote the rows of the walkers it updated (others zero)
+            for t in (chain, chain_lnp):
+                if self._dist.get_backend(self.group) == "gloo":
+                    h = t.cpu()
+                    self._dist.all_reduce(h, group=self.group)
+                    t.copy_(h)
+                else:
+                    self._dist.all_reduce(t, group=self.group)
+        return True
+
     # --- sampling ---------------------------------------------------------------------------------------
     def run_mcmc(self, initial_state, nsteps, progress=False, store=True):
         import torch
+        from .engine import EngineError, RX_E_TIMEOUT
         if isinstance(initial_state, State):
             coords, lp = initial_state.coords, initial_state.log_prob
         else:
@@ -561,28 +664,50 @@ class DeviceEnsembleSampler:
             raise ValueError("The initial log_prob was NaN")
         nsteps = int(nsteps)
         chain = chain_lnp = None
+        peer = (self.engine is not None and self._sharded and self.schedule == "dataflow" and not self.time_solves
+                and nsteps > 0 and (self.peer_state is True or (self.peer_state is None and self._peer_setup())))
         if store and nsteps > 0:
-            chain = torch.empty(nsteps, self.N, self.ndim, dtype=torch.float64, device=self.coords.device)
-            chain_lnp = torch.empty(nsteps, self.N, dtype=torch.float64, device=self.coords.device)
-        dataflow = self.engine is not None and not self._sharded and self.schedule == "dataflow" and not self.time_solves
-        if dataflow:
+            # (peer schedule: every rank fills the rows of the walkers it updated, the sum over ranks is the chain)
+            alloc = torch.zeros if peer else torch.empty
+            chain = alloc(nsteps, self.N, self.ndim, dtype=torch.float64, device=self.coords.device)
+            chain_lnp = alloc(nsteps, self.N, dtype=torch.float64, device=self.coords.device)
+        self.last_schedule = "halfsteps"
+        if peer:
+            start = (self.coords.clone(), self.lnp.clone(), self.naccept.clone())
+            if self._run_peer(nsteps, chain, chain_lnp):
+                self.last_schedule = "dataflow-peer"
+            else:
+                if not self.fallback:
+                    raise EngineError("multi-GPU dataflow sampler: a task waited longer than the timeout", RX_E_TIMEOUT)
+                import warnings
+                warnings.warn("dataflow sampler abandoned its run (timeout on some rank); repeating it per half-step")
+                self.coords.copy_(start[0]); self.lnp.copy_(start[1]); self.naccept.copy_(start[2])
+                peer = False
+        dataflow = (self.engine is not None and not self._sharded and self.schedule == "dataflow" and not self.time_solves)
+        if peer:
+            pass
+        elif dataflow:
             start = (self.coords.clone(), self.lnp.clone(), self.naccept.clone())
             try:
                 self.engine.sampler_run_async_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed,
                                                     self.step_counter, nsteps, self.coords, self.lnp, self.naccept,
                                                     chain, chain_lnp, ens_src=self.ens_src)
                 self.engine.sampler_wait(self.coords.device)
-            except Exception as exc:
-                if not self.fallback:
+            except EngineError as exc:
+                # only the sampler's own give-up (RX_E_TIMEOUT: a task waited longer than the timeout, the
+                # grid drained) is retried; argument errors, RX_E_UNSUPP and HIP faults are the caller's
+                if exc.rc != RX_E_TIMEOUT or not self.fallback:
                     raise
-                # a task gave up waiting (never observed in practice): the same chain under the half-step
-                # schedule, from the state this call started with
+                # (never observed in practice): the same chain under the half-step schedule, from the
+                # state this call started with
                 import warnings
                 warnings.warn("dataflow sampler abandoned its run (%s); repeating it per half-step" % exc)
                 self.coords.copy_(start[0]); self.lnp.copy_(start[1]); self.naccept.copy_(start[2])
                 dataflow = False
-        if dataflow:
+        if peer:
             pass
+        elif dataflow:
+            self.last_schedule = "dataflow"
         elif self.engine is not None and not self._sharded:
             # one call enqueues every kernel of every step on the current stream
             self.last_solve_ms = self.engine.sampler_run_torch(
@@ -602,8 +727,9 @@ class DeviceEnsembleSampler:
         self.step_counter += nsteps
         self.iteration += nsteps
         if chain is not None:
-            self._chain.append(chain)
-            self._chain_lnp.append(chain_lnp)
+            # finished blocks leave HBM (65536 walkers x 1000 steps are 2 GB per call): get_chain joins them on the host
+            self._chain.append(chain.cpu().numpy())
+            self._chain_lnp.append(chain_lnp.cpu().numpy())
         shape = (self.N, self.ndim) if self.nens == 1 else (self.nens, self.nwalkers, self.ndim)
         lshape = (self.N,) if self.nens == 1 else (self.nens, self.nwalkers)
         return State(self.coords.cpu().numpy().reshape(shape), self.lnp.cpu().numpy().reshape(lshape))

@@ -1,0 +1,191 @@
+"""The dataflow sampler across ranks (rx_sampler_peer_*: replicas of the sampler's shared state written by
+peers): the multi-GPU form of the reference's Pool.map over walkers [/root/reference/emcee/emcee_radex.py:
+480-488], rehearsed on ONE GPU -- (i) two handles in one process, their replicas exchanged as device
+pointers, two kernels on two streams; (ii) two processes that share GPU 0 and map each other's replica
+through hipIpcGetMemHandle / hipIpcOpenMemHandle, exactly the code path of one process per GPU.  The bar is
+the one the schedule promises: the chain of the one-GPU dataflow run, bit for bit (positions,
+log-probabilities, acceptance counts, stored chain)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O                      # noqa: E402  (checker only)
+from radex_emcee_amd import workloads               # noqa: E402
+from radex_emcee_amd.engine import Engine           # noqa: E402
+from test_gpu_parity import _truth_source           # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mol(co_path):
+    return O.Molecule(co_path)
+
+
+def _setup(e, mol, shape, nw):
+    """source slot 0 of engine e for the config-2 (1 component) or config-4 (2 components) shape; start positions"""
+    if shape == "config2":
+        cfg = workloads.config2(nw, seed=77)
+        _truth_source(e, mol, cfg)
+        return cfg["walkers"], 1
+    cfg = workloads.config4(nw)
+    e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"], 2, cfg["T_d"])
+    tf = e.model_flux_batch(cfg["truth"][None, :])[0]
+    e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"], 2, cfg["T_d"])
+    return cfg["walkers"], 2
+
+
+@pytest.mark.parametrize("shape,nw,nsteps", [("config2", 1024, 14), ("config4", 256, 5)])
+def test_peer_dataflow_two_handles_one_process(co_path, mol, shape, nw, nsteps):
+    """Two ranks = two handles on GPU 0, each running its block of every half-step in its own persistent
+    kernel (half the CUs each, two streams) and publishing into both replicas.  More steps than the ring of
+    versions holds (config 2: 14 > 12), so the per-step counters are exercised across ranks too."""
+    import torch
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler
+    dev = torch.device("cuda", 0)
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    engs = [Engine(co_path), Engine(co_path)]
+    for e in engs:
+        p0, ncomp = _setup(e, mol, shape, nw)
+        e.set_sampler_grid_limit(ncu // 2)
+    ndim = 4 * ncomp
+    ref = DeviceEnsembleSampler(nw, ndim, engine=engs[0], seed=5)            # one GPU, one kernel: the reference chain
+    st_ref = ref.run_mcmc(p0, nsteps)
+    assert ref.last_schedule == "dataflow"
+    lnp0 = ref.compute_log_prob(p0)
+    for r, e in enumerate(engs):
+        e.sampler_peer_setup(2, r, 1, nw, ncomp, export=False)
+    bases = [e.sampler_peer_base() for e in engs]
+    assert all(bases)
+    streams = [torch.cuda.Stream(device=dev) for _ in engs]
+    state = []
+    for r, e in enumerate(engs):
+        e.sampler_peer_connect(bases=bases)
+        coords = torch.from_numpy(np.ascontiguousarray(p0)).to(dev)
+        lnp = lnp0.clone()
+        nacc = torch.zeros(nw, dtype=torch.int32, device=dev)
+        chain = torch.zeros(nsteps, nw, ndim, dtype=torch.float64, device=dev)
+        chain_lnp = torch.zeros(nsteps, nw, dtype=torch.float64, device=dev)
+        state.append((coords, lnp, nacc, chain, chain_lnp))
+    torch.cuda.synchronize()
+    for r, e in enumerate(engs):
+        e.sampler_peer_begin(*state[r][:3], stream=streams[r].cuda_stream)
+    # (both replicas are seeded: the barrier of the multi-process form)
+    for r, e in enumerate(engs):
+        e.sampler_peer_run(2.0, 5, 0, nsteps, dev, state[r][3], state[r][4], stream=streams[r].cuda_stream)
+    for r, e in enumerate(engs):
+        e.sampler_wait(dev, stream=streams[r].cuda_stream)
+    for r, e in enumerate(engs):
+        e.sampler_peer_finish(*state[r][:3], stream=streams[r].cuda_stream)
+    torch.cuda.synchronize()
+    for r in range(2):
+        assert np.array_equal(state[r][0].cpu().numpy(), st_ref.coords), "rank %d: final positions differ" % r
+        assert np.array_equal(state[r][1].cpu().numpy(), st_ref.log_prob)
+        assert np.array_equal(state[r][2].cpu().numpy() / float(nsteps), ref.acceptance_fraction)
+    chain = (state[0][3] + state[1][3]).cpu().numpy()
+    chain_lnp = (state[0][4] + state[1][4]).cpu().numpy()
+    assert np.array_equal(chain, ref.get_chain()) and np.array_equal(chain_lnp, ref.get_log_prob())
+    # every row of the chain was written by exactly one rank
+    w0, w1 = (state[0][4] != 0).cpu().numpy(), (state[1][4] != 0).cpu().numpy()
+    assert not (w0 & w1).any() and (w0 | w1).all() and w0.sum() == w1.sum()
+    for e in engs:
+        e.sampler_peer_close()
+        e.close()
+
+
+def test_peer_dataflow_one_rank_group(co_path, mol):
+    """A group of ONE rank runs the same kernel in its one-GPU form on the replica block."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler
+    e = Engine(co_path)
+    p0, _ = _setup(e, mol, "config2", 256)
+    ref = DeviceEnsembleSampler(256, 4, engine=e, seed=9)
+    st_ref = ref.run_mcmc(p0, 6)
+    import torch.distributed as dist
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        d = DeviceEnsembleSampler(256, 4, engine=e, seed=9, group=dist.group.WORLD)
+        st = d.run_mcmc(p0, 6)
+        assert d.last_schedule == "dataflow-peer" and d.peer_state is True
+        assert np.array_equal(st.coords, st_ref.coords) and np.array_equal(d.get_chain(), ref.get_chain())
+        assert np.array_equal(d.get_log_prob(), ref.get_log_prob())
+        st2 = d.run_mcmc(st, 3)                                     # a second call re-seeds the replica
+        st2_ref = ref.run_mcmc(st_ref, 3)
+        assert np.array_equal(st2.coords, st2_ref.coords)
+    finally:
+        dist.destroy_process_group()
+    e.close()
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+rank, world, port, out, shape, nw, nsteps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6], int(sys.argv[7]), int(sys.argv[8])
+import torch
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+from radex_emcee_amd import workloads
+from radex_emcee_amd.engine import Engine
+from radex_emcee_amd.sampler import DeviceEnsembleSampler, State
+e = Engine(device=0)                                   # every rank on GPU 0: the replicas travel as IPC handles
+if shape == "config2":
+    cfg = workloads.config2(nw, seed=77); ncomp = 1
+    e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
+    tf = e.model_flux_batch(cfg["truth"][None, :])[0]
+    e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"])
+else:
+    cfg = workloads.config4(nw); ncomp = 2
+    e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"], 2, cfg["T_d"])
+    tf = e.model_flux_batch(cfg["truth"][None, :])[0]
+    e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"], 2, cfg["T_d"])
+d = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5, group=dist.group.WORLD)
+d.fallback = False                                     # a timeout is a failure here, not a silent half-step run
+st = d.run_mcmc(cfg["walkers"], nsteps)
+st = d.run_mcmc(st, 3)                                 # a second call: replica re-seeded, step counter continues
+np.savez(out + "/peer_%d.npz" % rank, coords=st.coords, lnp=st.log_prob, chain=d.get_chain(), chain_lnp=d.get_log_prob(),
+         acc=d.acceptance_fraction, schedule=np.array(d.last_schedule), peer=np.array(str(d.peer_state)))
+dist.barrier(); dist.destroy_process_group()
+e.close()
+'''
+
+
+@pytest.mark.parametrize("shape,nw,nsteps", [("config2", 1024, 13), ("config4", 256, 4)])
+def test_peer_dataflow_two_processes_ipc(co_path, mol, tmp_path, shape, nw, nsteps):
+    """One process per rank, both on GPU 0, DeviceEnsembleSampler(group=...): the replicas are exported with
+    hipIpcGetMemHandle and mapped with hipIpcOpenMemHandle -- the code path of one process per GPU -- and the
+    chain equals the one-GPU dataflow chain bit for bit on every rank."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "peer_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", str(port), str(tmp_path), shape, str(nw),
+                               str(nsteps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    e = Engine(co_path)
+    p0, ncomp = _setup(e, mol, shape, nw)
+    ref = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5)
+    st = ref.run_mcmc(p0, nsteps)
+    st = ref.run_mcmc(st, 3)
+    for r in range(2):
+        z = np.load(tmp_path / ("peer_%d.npz" % r))
+        assert str(z["schedule"]) == "dataflow-peer", (str(z["schedule"]), str(z["peer"]))
+        assert np.array_equal(z["coords"], st.coords) and np.array_equal(z["lnp"], st.log_prob)
+        assert np.array_equal(z["chain"], ref.get_chain()) and np.array_equal(z["chain_lnp"], ref.get_log_prob())
+        assert np.array_equal(z["acc"], ref.acceptance_fraction)
+    e.close()
