@@ -13,11 +13,26 @@ lubksb_ -> sgeir_/sgefa_/sgesl_) can be executed in-process once the image is
 mapped:  segments are mmap'ed at one contiguous slide, rebase fix-ups applied,
 and the lazy/non-lazy symbol pointers bound.  libm/libc imports (exp, log,
 log10, pow, malloc, free, memcpy, memset, __bzero) are bound to glibc.  Every
-other import (libgfortran I/O, CPython API) is bound to a *trap* that records
-its name; a vector is only accepted when no trap fired, i.e. when no Fortran
-I/O / error path was executed.  readdata_ (libgfortran list-directed READ)
-therefore cannot be run; COMMON blocks are populated directly, exactly as
-pyradex itself pokes them (emcee/pyradex/core.py:476-482, 853-854).
+other import (CPython API, STOP, ...) is bound to a *trap* that records
+its name; a vector is only accepted when no trap fired, i.e. when no error
+path was executed.
+
+readdata_ (called by the reference at emcee/pyradex/core.py:570,744) reads the
+LAMDA file through libgfortran.3's OPEN / list-directed READ / CLOSE.  Those
+eleven entry points (st_open, st_read, transfer_integer/real/character,
+st_read_done, st_close and the WRITE family used for its warnings) are served
+by `_FortranIO` below: a minimal implementation of exactly the statement forms
+readdata_ compiles to (OPEN(unit, file=, status='old'), READ(unit,*) items,
+READ(unit,'(a)') string, READ(unit,'(i1,a)') id, string), operating on the st_parameter_* fields the binary
+itself fills in (offsets read from the disassembly at radex.so@0x1cfaf-0x1d014,
+@0x1d065-0x1d0ab).  Decimal -> double conversion is Python's float(), which is
+correctly rounded like the strtod libgfortran calls.  Anything outside those
+forms (repeat counts, null values, slashes, end of file, a malformed number)
+is recorded as a trap, so such a vector is rejected instead of guessed.
+The numbers readdata_ produces from the file -- xnu, crate, ctot -- are then
+the reference's own (tests/golden/make_ref_readdata.py -> ref_readdata.json).
+Other COMMON state is populated directly, exactly as pyradex itself pokes it
+(emcee/pyradex/core.py:476-482, 853-854).
 
 Nothing from the reference is copied into the repo: only numbers it computes.
 """
@@ -102,6 +117,183 @@ class MachO:
         self.vmsize = max(v + s for _, v, s, _, _ in self.segments)
 
 
+class _FortranIO:
+    """libgfortran.3 I/O entry points as readdata_ uses them (see the module docstring).
+
+    st_parameter_common: flags u32 @0, unit i32 @4, filename @8, line i32 @16.
+    st_parameter_open:   file_len i32 @0x2c, file @0x30, status @0x38, status_len i32 @0x40.
+    st_parameter_dt:     format @0x48, format_len i32 @0x50.
+    flags: 0x80 = list-directed, 0x1000 = has a format; low two bits = library return code."""
+
+    F_LIST, F_FORMAT = 0x80, 0x1000
+
+    def __init__(self, trap_log):
+        self.trap_log = trap_log
+        self.units = {}            # unit -> [records, next record]
+        self.stmt = {}             # address of the statement's parameter block -> state
+        self.messages = []         # what the routine WROTE (its warnings), for information
+        self.opened = []
+
+    @staticmethod
+    def _i32(addr):
+        return C.c_int32.from_address(addr)
+
+    @staticmethod
+    def _u32(addr):
+        return C.c_uint32.from_address(addr)
+
+    def _bad(self, what):
+        self.trap_log.append("fortran-io: " + what)
+
+    # ---- OPEN / CLOSE -----------------------------------------------------------------------------
+    def st_open(self, dt):
+        n = self._i32(dt + 0x2c).value
+        name = C.string_at(C.c_void_p.from_address(dt + 0x30).value, n).decode("latin-1").rstrip(" ")
+        unit = self._i32(dt + 4).value
+        flags = self._u32(dt)
+        try:
+            with open(name, "r", newline="") as f:
+                recs = f.read().split("\n")
+        except OSError:
+            flags.value = (flags.value & ~3) | 1                      # IOPARM_LIBRETURN_ERROR: the routine's own err= path
+            return
+        if recs and recs[-1] == "":
+            recs.pop()
+        self.units[unit] = [[r.rstrip("\r") for r in recs], 0]
+        self.opened.append(name)
+        flags.value &= ~3
+
+    def st_close(self, dt):
+        self.units.pop(self._i32(dt + 4).value, None)
+
+    # ---- READ -----------------------------------------------------------------------------------------
+    def st_read(self, dt):
+        unit, flags = self._i32(dt + 4).value, self._u32(dt).value
+        if unit not in self.units:
+            self._bad("READ on unit %d which is not open" % unit)
+        if not flags & (self.F_LIST | self.F_FORMAT) or flags & ~(self.F_LIST | self.F_FORMAT | 3):
+            self._bad("READ statement form %#x not implemented" % flags)
+        fmt = None
+        if flags & self.F_FORMAT:
+            fmt = C.string_at(C.c_void_p.from_address(dt + 0x48).value, self._i32(dt + 0x50).value).decode().strip().lower()
+            if fmt not in ("(a)", "(i1,a)"):
+                self._bad("format %r not implemented" % fmt)
+        self.stmt[dt] = dict(unit=unit, fmt=fmt, rec=None, col=0)
+
+    def _next_record(self, st):
+        u = self.units.get(st["unit"])
+        if u is None or u[1] >= len(u[0]):
+            self._bad("end of file")
+            st["rec"], st["col"] = "", 0
+            return
+        st["rec"], st["col"] = u[0][u[1]], 0
+        u[1] += 1
+
+    def _token(self, st):
+        """next list-directed item: blanks separate, ONE comma may follow an item; records are consumed as needed"""
+        for _ in range(100000):
+            if st["rec"] is None:
+                self._next_record(st)
+            rec, c = st["rec"], st["col"]
+            while c < len(rec) and rec[c] in " \t":
+                c += 1
+            if c >= len(rec):
+                if "fortran-io: end of file" in self.trap_log:
+                    return "0"
+                st["rec"] = None
+                continue
+            if rec[c] in ",/":
+                self._bad("null value or slash in list-directed input")
+                return "0"
+            if rec[c] in "'\"":
+                q = rec[c]
+                e = rec.find(q, c + 1)
+                if e < 0 or (e + 1 < len(rec) and rec[e + 1] == q):
+                    self._bad("delimited string form not implemented")
+                    return ""
+                tok, c = rec[c + 1:e], e + 1
+            else:
+                b = c
+                while c < len(rec) and rec[c] not in " \t,/":
+                    c += 1
+                tok = rec[b:c]
+            while c < len(rec) and rec[c] in " \t":
+                c += 1
+            if c < len(rec) and rec[c] == ",":
+                c += 1
+            st["col"] = c
+            return tok
+        self._bad("runaway read")
+        return "0"
+
+    def transfer_integer(self, dt, p, kind):
+        st = self.stmt[dt]
+        if st["fmt"] == "(i1,a)" and st["rec"] is None:               # I1: the first column of a fresh record
+            self._next_record(st)
+            tok, st["col"] = st["rec"][:1].replace(" ", "0") or "0", 1   # (blanks read as zero: BN is not in effect... nor needed)
+        elif st["fmt"] is not None:
+            self._bad("integer item under format %r not implemented" % st["fmt"])
+            return
+        else:
+            tok = self._token(st)
+        t = tok[1:] if tok[:1] in "+-" else tok
+        if kind != 4 or not t.isdigit():
+            self._bad("bad integer %r" % tok)
+            return
+        C.c_int32.from_address(p).value = int(tok)
+
+    def transfer_real(self, dt, p, kind):
+        tok = self._token(self.stmt[dt])
+        t = tok.lower().replace("d", "e")
+        try:
+            if kind != 8 or "*" in t or not t or t.strip("+-.0123456789e") or "inf" in t or "nan" in t:
+                raise ValueError(t)
+            v = float(t)                                               # correctly rounded, like strtod
+        except ValueError:
+            self._bad("bad real %r" % tok)
+            return
+        C.c_double.from_address(p).value = v
+
+    def transfer_character(self, dt, p, n):
+        st = self.stmt[dt]
+        if st["fmt"] == "(a)":
+            self._next_record(st)
+            txt, st["col"] = st["rec"], len(st["rec"])
+        elif st["fmt"] == "(i1,a)":                                    # A without a width: the variable's length
+            if st["rec"] is None or st["col"] != 1:
+                self._bad("character item of (i1,a) out of order")
+                return
+            txt, st["col"] = st["rec"][1:1 + n], 1 + n
+        else:
+            txt = self._token(st)
+        C.memmove(p, txt[:n].ljust(n).encode("latin-1"), n)
+
+    def st_read_done(self, dt):
+        st = self.stmt.pop(dt, None)
+        if st is not None and st["rec"] is None and not any("end of file" in t for t in self.trap_log):
+            self._next_record(st)                                      # READ without items: skips one record
+
+    # ---- WRITE (warnings such as "Tkin lower than..."): recorded, never an error -----------------------
+    def st_write(self, dt):
+        self.stmt[dt] = dict(out=[])
+
+    def transfer_character_write(self, dt, p, n):
+        self.stmt.setdefault(dt, dict(out=[]))["out"].append(C.string_at(p, n).decode("latin-1"))
+
+    def transfer_integer_write(self, dt, p, kind):
+        v = C.c_int32.from_address(p).value if kind == 4 else C.c_int64.from_address(p).value
+        self.stmt.setdefault(dt, dict(out=[]))["out"].append(str(v))
+
+    def transfer_real_write(self, dt, p, kind):
+        v = C.c_double.from_address(p).value if kind == 8 else C.c_float.from_address(p).value
+        self.stmt.setdefault(dt, dict(out=[]))["out"].append(repr(v))
+
+    def st_write_done(self, dt):
+        st = self.stmt.pop(dt, None)
+        if st:
+            self.messages.append(" ".join(st["out"]))
+
+
 def _uleb(d, p):
     r = 0
     sh = 0
@@ -137,6 +329,7 @@ class RefRadex:
         self._rebase()
         self.trap_log = []
         self._keep = []
+        self.io = _FortranIO(self.trap_log)
         self._bind(libc)
         self._prototypes()
 
@@ -205,6 +398,16 @@ class RefRadex:
         self._keep.append(cb)
         return C.cast(cb, C.c_void_p).value
 
+    def _make_io(self, name):
+        """one libgfortran entry point served by _FortranIO: (dt) or (dt, pointer, kind / length)"""
+        fn = getattr(self.io, name)
+        if name.startswith("transfer_"):
+            cb = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)(lambda dt, p, k: fn(dt, p, k))
+        else:
+            cb = C.CFUNCTYPE(None, C.c_void_p)(lambda dt: fn(dt))
+        self._keep.append(cb)
+        return C.cast(cb, C.c_void_p).value
+
     def _bind(self, libc):
         libm = C.CDLL(ctypes.util.find_library("m") or "libm.so.6")
         real = {"exp": libm, "log": libm, "log10": libm, "pow": libm,
@@ -232,6 +435,8 @@ class RefRadex:
                     slot.value = C.cast(libc.bzero, C.c_void_p).value
                 elif bare == "__stack_chk_guard":
                     slot.value = C.addressof(guard)
+                elif bare.startswith("_gfortran_") and hasattr(self.io, bare[len("_gfortran_"):]):
+                    slot.value = self._make_io(bare[len("_gfortran_"):])
                 else:
                     slot.value = self._make_trap(bare)
 
@@ -248,6 +453,7 @@ class RefRadex:
         self.f_escprob = self._fn("_escprob_", C.c_double, pd)
         self.f_backrad = self._fn("_backrad_", None)
         self.f_lubksb = self._fn("_lubksb_", None, pd, pi, pi, pi, pd)
+        self.f_readdata = self._fn("_readdata_", None)
 
     def common_f64(self, name, byte_off, n):
         return np.ctypeslib.as_array((C.c_double * n).from_address(self.addr(name) + byte_off))
@@ -297,6 +503,28 @@ class RefRadex:
 
     def backrad(self):
         self.f_backrad()
+
+    def readdata(self, molfile: str, tkin: float, density_by_id: dict):
+        """The reference's own readdata_ on `molfile` (impex.molfile, 120 characters) with cphys.tkin and
+        cphys.density(id) set as the setters do (emcee/pyradex/core.py:401-402, 489-579): parses the LAMDA
+        file, fills imolec / rmolec / radi.xnu, interpolates the rates, detailed balance, ctot."""
+        if len(molfile) > 120:
+            raise ValueError("molfile path longer than the COMMON block's 120 characters")
+        C.memmove(self.addr("_impex_") + 0x78, molfile.ljust(120).encode(), 120)
+        v = self.views()
+        if getattr(self, "_molfile", None) not in (None, molfile):
+            # readdata_ keeps the interpolated rates of a partner in a static table that it only ever writes where the
+            # file lists a transition, and adds density * table into crate for every pair of levels: entries of ANOTHER
+            # molecule read earlier in the same image would leak in (seen: toy6 after co_synth).  The reference's
+            # process reads one molecule, so its unlisted pairs hold the zeros of a fresh image: one image per molecule.
+            raise ValueError("this image has read %s: map a fresh RefRadex for another molecule" % self._molfile)
+        self._molfile = molfile
+        v["density"][:] = 0.0
+        for k, x in density_by_id.items():
+            v["density"][int(k) - 1] = x
+        v["totdens"][0] = float(sum(density_by_id.values()))
+        v["tkin"][0] = tkin
+        self.f_readdata()
 
     def lubksb(self, a_colmajor: np.ndarray):
         """a: (np_, np_) Fortran-ordered; n = np_ (the reference passes nplus, maxlev)."""

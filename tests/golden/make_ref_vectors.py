@@ -9,12 +9,13 @@ machine code (/root/reference/emcee/pyradex/radex/radex.so, routines
 escprob_, backrad_, lubksb_, matrix_) loaded through oracle/macho_ref.py; the
 iteration driver around matrix_ follows emcee/pyradex/core.py:896-925.
 
-Inputs that the reference would obtain from readdata_ (which cannot run here:
-it needs libgfortran's list-directed READ) are poked into the COMMON blocks
-directly: level/line tables parsed from the committed LAMDA-format files and
-crate/ctot from the oracle's rate routine.  They are stored in the fixtures by
-value where small, otherwise they are re-derivable from the committed .dat
-file, so the vectors stay self-contained.
+The molecule tables and the collision rates are the reference's own too: its
+readdata_ parses the committed LAMDA-format files (co_synth.dat, toy6.dat) and
+interpolates / balances the rates for every case (oracle/macho_ref.py serves
+the handful of libgfortran I/O calls it makes).  Nothing the oracle computes is
+written into the binary's COMMON blocks; the oracle only helps to CHOOSE walkers
+(which ones run into maxiter).  readdata_'s outputs themselves are pinned by
+tests/golden/make_ref_readdata.py -> ref_readdata.json.
 
 A vector is rejected if any trapped import (Fortran I/O, STOP) fired.
 """
@@ -150,6 +151,7 @@ def main():
         ("toy6", 1, 2.73, {1: 1e3}, 10.0, 1e16),
     ]
     out_b, out_m = [], []
+    images = {}
     mols = {k: O.Molecule(p) for k, p in molfiles.items()}
     # walkers drawn like BASELINE config 2 (uniform in the prior box, z=2.5); keep the
     # first three that exhaust maxiter=200 in the oracle plus eight others
@@ -177,10 +179,18 @@ def main():
         st.set_density(dens)
         st.s.tkin = tkin
         st.s.cdmol = cdmol
-        assert st.rates() == 0
-        # wipe + poke
-        poke_molecule(R, v, mol)
-        poke_physics(R, v, st, mol, method)
+        # the reference's own parser, rate interpolation and detailed balance on the committed file
+        # (one mapped image per molecule, like one reference process per molecule: see RefRadex.readdata)
+        R = images.setdefault(name, RefRadex())
+        v = R.views()
+        R.readdata(molfiles[name], tkin, dens)
+        assert v["imolec_hdr"][0] == mol.nlev and v["imolec_hdr"][1] == mol.nline
+        v["method"][0] = method
+        v["cdmol"][0] = cdmol
+        v["deltav"][0] = st.s.deltav
+        v["xpop"][:mol.nlev] = 0.0
+        v["tex"][:mol.nline] = 0.0
+        v["taul"][:mol.nline] = 0.0
         v["tbg"][0] = tbg
         R.backrad()
         out_b.append(dict(mol=name, tbg=tbg, backi=fl(v["backi"][:mol.nline]),
@@ -194,10 +204,12 @@ def main():
                           xpop=fl(v["xpop"][:mol.nlev]), tex=fl(v["tex"][:mol.nline]),
                           taul=fl(v["taul"][:mol.nline])))
         print(name, method, tkin, cdmol, "-> niter", it, "conv", conv)
+    for im in images.values():
+        assert not im.trap_log, im.trap_log
     json.dump(dict(source="radex.so:_backrad_", cases=out_b),
               open(os.path.join(HERE, "ref_backrad.json"), "w"), indent=0)
     json.dump(dict(source="radex.so:_matrix_ driven by core.py:896-925 (cold start)",
-                   note="crate/ctot poked from oracle rxo_rates(); see make_ref_vectors.py",
+                   note="molecule tables, crate and ctot by the binary's own readdata_ on the committed .dat files",
                    cases=out_m), open(os.path.join(HERE, "ref_matrix.json"), "w"), indent=0)
     print("traps:", R.trap_log)
 

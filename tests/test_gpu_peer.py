@@ -18,7 +18,6 @@ pytestmark = pytest.mark.gpu
 from oracle import oracle as O                      # noqa: E402  (checker only)
 from radex_emcee_amd import workloads               # noqa: E402
 from radex_emcee_amd.engine import Engine           # noqa: E402
-from test_gpu_parity import _truth_source           # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -32,7 +31,9 @@ def _setup(e, mol, shape, nw):
     """source slot 0 of engine e for the config-2 (1 component) or config-4 (2 components) shape; start positions"""
     if shape == "config2":
         cfg = workloads.config2(nw, seed=77)
-        _truth_source(e, mol, cfg)
+        e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
+        tf = e.model_flux_batch(cfg["truth"][None, :])[0]               # (the workers below make the same SLED)
+        e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"])
         return cfg["walkers"], 1
     cfg = workloads.config4(nw)
     e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"], 2, cfg["T_d"])
@@ -41,18 +42,35 @@ def _setup(e, mol, shape, nw):
     return cfg["walkers"], 2
 
 
-@pytest.mark.parametrize("shape,nw,nsteps", [("config2", 1024, 14), ("config4", 256, 5)])
-def test_peer_dataflow_two_handles_one_process(co_path, mol, shape, nw, nsteps):
-    """Two ranks = two handles on GPU 0, each running its block of every half-step in its own persistent
-    kernel (half the CUs each, two streams) and publishing into both replicas.  More steps than the ring of
-    versions holds (config 2: 14 > 12), so the per-step counters are exercised across ranks too."""
-    import torch
-    from radex_emcee_amd.sampler import DeviceEnsembleSampler
-    dev = torch.device("cuda", 0)
-    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-    engs = [Engine(co_path), Engine(co_path)]
+INPROC = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+from radex_emcee_amd import workloads
+from radex_emcee_amd.engine import Engine
+from radex_emcee_amd.sampler import DeviceEnsembleSampler
+dev = torch.device("cuda", 0)
+ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+def setup(e, shape, nw):
+    if shape == "config2":
+        cfg = workloads.config2(nw, seed=77); nc = 1
+        e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
+        tf = e.model_flux_batch(cfg["truth"][None, :])[0]
+        e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"])
+    else:
+        cfg = workloads.config4(nw); nc = 2
+        e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"], 2, cfg["T_d"])
+        tf = e.model_flux_batch(cfg["truth"][None, :])[0]
+        e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"], 2, cfg["T_d"])
+    return cfg["walkers"], nc
+
+for shape, nw, nsteps in (("config2", 1024, 14), ("config4", 256, 5)):
+    engs = [Engine(), Engine()]
     for e in engs:
-        p0, ncomp = _setup(e, mol, shape, nw)
+        p0, ncomp = setup(e, shape, nw)
         e.set_sampler_grid_limit(ncu // 2)
     ndim = 4 * ncomp
     ref = DeviceEnsembleSampler(nw, ndim, engine=engs[0], seed=5)            # one GPU, one kernel: the reference chain
@@ -63,16 +81,12 @@ def test_peer_dataflow_two_handles_one_process(co_path, mol, shape, nw, nsteps):
         e.sampler_peer_setup(2, r, 1, nw, ncomp, export=False)
     bases = [e.sampler_peer_base() for e in engs]
     assert all(bases)
-    streams = [torch.cuda.Stream(device=dev) for _ in engs]
     state = []
     for r, e in enumerate(engs):
         e.sampler_peer_connect(bases=bases)
-        coords = torch.from_numpy(np.ascontiguousarray(p0)).to(dev)
-        lnp = lnp0.clone()
-        nacc = torch.zeros(nw, dtype=torch.int32, device=dev)
-        chain = torch.zeros(nsteps, nw, ndim, dtype=torch.float64, device=dev)
-        chain_lnp = torch.zeros(nsteps, nw, dtype=torch.float64, device=dev)
-        state.append((coords, lnp, nacc, chain, chain_lnp))
+        state.append((torch.from_numpy(np.ascontiguousarray(p0)).to(dev), lnp0.clone(), torch.zeros(nw, dtype=torch.int32, device=dev),
+                      torch.zeros(nsteps, nw, ndim, dtype=torch.float64, device=dev),
+                      torch.zeros(nsteps, nw, dtype=torch.float64, device=dev)))
     torch.cuda.synchronize()
     for r, e in enumerate(engs):
         e.sampler_peer_begin(*state[r][:3], stream=streams[r].cuda_stream)
@@ -97,6 +111,24 @@ def test_peer_dataflow_two_handles_one_process(co_path, mol, shape, nw, nsteps):
     for e in engs:
         e.sampler_peer_close()
         e.close()
+    print("OK", shape, nw, nsteps, flush=True)
+'''
+
+
+def test_peer_dataflow_two_handles_one_process(tmp_path):
+    """Two ranks = two handles on GPU 0, each running its block of every half-step in its own persistent
+    kernel (half the CUs each, two streams) and publishing into both replicas; config-2 and config-4 shapes.
+    More steps than the ring of versions holds (config 2: 14 > 12), so the per-step counters are exercised
+    across ranks too.  In its own process with GPU_MAX_HW_QUEUES=8: two kernels that wait for each other must
+    sit in different hardware queues, and HIP deals a process's streams onto 4 queues by default (a pair of
+    streams that shares one never runs concurrently -- an artefact of ranks inside ONE process; the
+    one-process-per-rank form below needs nothing of the kind)."""
+    script = tmp_path / "inproc.py"
+    script.write_text(INPROC)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=420, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK ") == 2
 
 
 def test_peer_dataflow_one_rank_group(co_path, mol):
