@@ -213,10 +213,12 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        import datetime
+        tmo = datetime.timedelta(seconds=240)          # a rank that died must not hold the others for the default half hour
         if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo,
                                     device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
@@ -349,69 +351,74 @@ def main():
             return time.perf_counter() - ts
 
         for name, ndim, nwk, nst in (("config4", 8, 2048, 12), ("config5", 4, 65536, 6)):
-            if name == "config4":
-                c = workloads.config4(nwk)
-                eng.set_source(c["tbg"], c["Jup"], np.ones(10), np.ones(10), c["bounds"], 2, c["T_d"], src=1)
-                tf = eng.model_flux_batch(c["truth"][None, :], src=1)[0]
-                eng.set_source(c["tbg"], c["Jup"], tf, 0.1 * tf, c["bounds"], 2, c["T_d"], src=1)
-                ens_src = [1]
-            else:
-                c = workloads.config2(nwk, seed=5678)
-                ens_src = None
-            rec = {"walkers": nwk, "ndim": ndim, "steps": nst, "scaling": "strong", "n_gpus": n_confirmed,
-                   "proposals_per_half_step": nwk // 2, "proposals_per_rank": -(-(nwk // 2) // world)}
+            try:
+                if name == "config4":
+                    c = workloads.config4(nwk)
+                    eng.set_source(c["tbg"], c["Jup"], np.ones(10), np.ones(10), c["bounds"], 2, c["T_d"], src=1)
+                    tf = eng.model_flux_batch(c["truth"][None, :], src=1)[0]
+                    eng.set_source(c["tbg"], c["Jup"], tf, 0.1 * tf, c["bounds"], 2, c["T_d"], src=1)
+                    ens_src = [1]
+                else:
+                    c = workloads.config2(nwk, seed=5678)
+                    ens_src = None
+                rec = {"walkers": nwk, "ndim": ndim, "steps": nst, "scaling": "strong", "n_gpus": n_confirmed,
+                       "proposals_per_half_step": nwk // 2, "proposals_per_rank": -(-(nwk // 2) // world)}
 
-            def entry(d, schedule, collective, base=None):
-                e = {"schedule": schedule, "collective": collective, "ms_per_step": round(d / nst * 1e3, 3),
-                     "walker_steps_per_s": round(nwk * nst / d, 1), "solves_per_s": round(nwk * nst * (ndim // 4) / d, 1)}
-                if base is not None:
-                    e["speedup_vs_1gpu_dataflow"] = round(base / d, 3)
-                return e
+                def entry(d, schedule, collective, base=None):
+                    e = {"schedule": schedule, "collective": collective, "ms_per_step": round(d / nst * 1e3, 3),
+                         "walker_steps_per_s": round(nwk * nst / d, 1), "solves_per_s": round(nwk * nst * (ndim // 4) / d, 1)}
+                    if base is not None:
+                        e["speedup_vs_1gpu_dataflow"] = round(base / d, 3)
+                    return e
 
-            # (1) ONE GPU, the dataflow kernel: the number every multi-GPU schedule has to beat (rank 0 alone)
-            d1 = 0.0
-            if rank == 0:
-                smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src)
-                state = smp.run_mcmc(c["walkers"], 1, store=False)
-                torch.cuda.synchronize()
-                ts = time.perf_counter()
-                smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
-                torch.cuda.synchronize()
-                d1 = time.perf_counter() - ts
-                del smp
-            d1 = max_over_ranks(d1)
-            rec["one_gpu_dataflow"] = entry(d1, "dataflow: one persistent kernel on ONE GPU (rank 0 alone)", "none")
-            if use_dist:
-                grp = dist.group.WORLD
-                # (2) the same ensemble across the ranks, dataflow with peer writes (falls back by itself)
-                smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp)
-                d2 = max_over_ranks(timed_run(smp, c["walkers"], nst))
-                used = smp.last_schedule
-                rec["multi_gpu_dataflow"] = entry(
-                    d2, "dataflow-peer: one persistent kernel per rank, every result published into all replicas "
-                        "(IPC-mapped fine-grained memory, system-scope stores over xGMI)" if used == "dataflow-peer"
-                    else "peer replicas unavailable (%s): half-steps + all_gather" % smp.peer_state,
-                    "none on the data path; two host barriers per run_mcmc call" if used == "dataflow-peer"
-                    else "all_gather_into_tensor per half-step", d1)
-                rec["multi_gpu_dataflow"]["ranks_share_one_gpu"] = bool(share)
-                del smp
-                # (3) north_star's literal form: block evaluation per rank + ONE all_gather of log-probabilities per half-step
-                smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp, schedule="halfsteps")
-                d3 = max_over_ranks(timed_run(smp, c["walkers"], nst))
-                rec["multi_gpu_halfsteps_allgather"] = entry(
-                    d3, "half-steps: propose, block evaluation per rank, all-gather, accept",
-                    "all_gather_into_tensor of %d f64 per half-step (%s)"
-                    % (nwk // 2, "gloo rehearsal, host copies" if share else "RCCL, device"), d1)
-                del smp
-                best = rec["multi_gpu_dataflow"] if d2 <= d3 else rec["multi_gpu_halfsteps_allgather"]
-            else:
-                best = rec["one_gpu_dataflow"]
-            # the line of this shape: the best schedule at this N, next to the one-GPU dataflow number
-            rec.update({"ms_per_step": best["ms_per_step"], "walker_steps_per_s": best["walker_steps_per_s"],
-                        "solves_per_s": best["solves_per_s"], "schedule": best["schedule"],
-                        "collective": best["collective"],
-                        "speedup_vs_1gpu_dataflow": best.get("speedup_vs_1gpu_dataflow", 1.0)})
-            sharded[name] = rec
+                # (1) ONE GPU, the dataflow kernel: the number every multi-GPU schedule has to beat (rank 0 alone)
+                d1 = 0.0
+                if rank == 0:
+                    smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src)
+                    state = smp.run_mcmc(c["walkers"], 1, store=False)
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
+                    torch.cuda.synchronize()
+                    d1 = time.perf_counter() - ts
+                    del smp
+                d1 = max_over_ranks(d1)
+                rec["one_gpu_dataflow"] = entry(d1, "dataflow: one persistent kernel on ONE GPU (rank 0 alone)", "none")
+                if use_dist:
+                    grp = dist.group.WORLD
+                    # (2) the same ensemble across the ranks, dataflow with peer writes (falls back by itself)
+                    smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp)
+                    d2 = max_over_ranks(timed_run(smp, c["walkers"], nst))
+                    used = smp.last_schedule
+                    rec["multi_gpu_dataflow"] = entry(
+                        d2, "dataflow-peer: one persistent kernel per rank, every result published into all replicas "
+                            "(IPC-mapped fine-grained memory, system-scope stores over xGMI)" if used == "dataflow-peer"
+                        else ("the peer-write dataflow run was abandoned (a task timed out): repeated per half-step"
+                              if smp.peer_state is True else
+                              "peer replicas unavailable (%s): half-steps + all_gather" % smp.peer_state),
+                        "none on the data path; two host barriers per run_mcmc call" if used == "dataflow-peer"
+                        else "all_gather_into_tensor per half-step", d1)
+                    rec["multi_gpu_dataflow"]["ranks_share_one_gpu"] = bool(share)
+                    del smp
+                    # (3) north_star's literal form: block evaluation per rank + ONE all_gather of log-probabilities per half-step
+                    smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp, schedule="halfsteps")
+                    d3 = max_over_ranks(timed_run(smp, c["walkers"], nst))
+                    rec["multi_gpu_halfsteps_allgather"] = entry(
+                        d3, "half-steps: propose, block evaluation per rank, all-gather, accept",
+                        "all_gather_into_tensor of %d f64 per half-step (%s)"
+                        % (nwk // 2, "gloo rehearsal, host copies" if share else "RCCL, device"), d1)
+                    del smp
+                    best = rec["multi_gpu_dataflow"] if d2 <= d3 else rec["multi_gpu_halfsteps_allgather"]
+                else:
+                    best = rec["one_gpu_dataflow"]
+                # the line of this shape: the best schedule at this N, next to the one-GPU dataflow number
+                rec.update({"ms_per_step": best["ms_per_step"], "walker_steps_per_s": best["walker_steps_per_s"],
+                            "solves_per_s": best["solves_per_s"], "schedule": best["schedule"],
+                            "collective": best["collective"],
+                            "speedup_vs_1gpu_dataflow": best.get("speedup_vs_1gpu_dataflow", 1.0)})
+                sharded[name] = rec
+            except Exception as exc:                     # (an error every rank sees alike: recorded, the line still prints)
+                sharded[name] = {"walkers": nwk, "ndim": ndim, "n_gpus": n_confirmed, "error": "%s: %s" % (type(exc).__name__, exc)}
         if not args.no_config3:
             # BASELINE configs[2] across GPUs: independent ensembles need no exchange at all -- rank r advances
             # its 16 / N sources (1024 walkers each) with the dataflow sampler; replicas, no collective

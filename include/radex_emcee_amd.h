@@ -212,8 +212,8 @@ int rx_set_sampler_timeout_ms(rx_handle *h, double ms);
  *                            first and sum over ranks);  rx_sampler_wait            ... barrier ...
  *   rx_sampler_peer_finish   final state -> d_coords / d_lnp / d_naccept; RX_E_TIMEOUT if a task on ANY rank
  *                            gave up waiting (every rank then reports it)
- *   rx_set_sampler_grid_limit  at most `blocks` workgroups per dataflow launch (0 = the whole GPU): ranks that
- *                            SHARE one GPU (rehearsals) must all be resident at once                        */
+ *   rx_set_sampler_grid_limit  rx_sampler_peer_run occupies at most `cus` compute units (0 = the whole GPU): ranks
+ *                            that SHARE one GPU (rehearsals) must all be resident at once                   */
 int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwalkers, int ncomp,
                           void *ipc_handle_out);
 void *rx_sampler_peer_base(rx_handle *h);
@@ -225,7 +225,7 @@ int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, in
 int rx_sampler_peer_finish(rx_handle *h, double *d_coords, double *d_lnp, int32_t *d_naccept,
                            void *stream);
 int rx_sampler_peer_close(rx_handle *h);
-int rx_set_sampler_grid_limit(rx_handle *h, int blocks);
+int rx_set_sampler_grid_limit(rx_handle *h, int cus);
 /* Counters of the dataflow sampler's launches (benchmarks; off by default): waits for the handle's work,
  * copies the counters accumulated since the last call into out6 (may be NULL), zeroes them and switches the
  * counting on (enable = 1) or off for the launches that follow.  out6: [0] tasks, [1] tasks whose proposal

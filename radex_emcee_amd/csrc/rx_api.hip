@@ -209,7 +209,7 @@ struct rx_handle {
     uint32_t *d_abort = nullptr;
     uint32_t *h_abort = nullptr;     // pinned mirror, filled by an async copy behind every async run
     long long sampler_timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock: far beyond any real wait
-    int sampler_grid_limit = 0;      // > 0: at most this many workgroups per dataflow launch (ranks sharing one GPU)
+    int sampler_grid_limit = 0;      // > 0: the dataflow launches of the peer form occupy at most this many CUs (ranks sharing one GPU)
     unsigned long long *d_stats = nullptr;   // [8] counters of the dataflow launches since the last rx_sampler_stats
     int stats_on = 0;
     // multi-GPU dataflow sampler (rx_sampler_peer_*): this rank's replica block and the peers' blocks as mapped here
@@ -248,6 +248,8 @@ int hip_fail(rx_handle *h, hipError_t e, const char *what)
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail((h), e_, #call); } while (0)
 
 typedef void (*kernel_fn)(const RxKArgs);
+
+static bool is_exact(const rx_handle *h) { return h->mol.nlev == h->NL; }   // the molecule fills the instantiation: no padding levels
 typedef void (*lukernel_fn)(const double *, double *, int32_t *, int, int);
 
 lukernel_fn lukernel_for(int NL)
@@ -474,7 +476,7 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     const long cap = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    kernel_fn k = kernel_for(h->NL, occ, h->mol.nlev == h->NL);
+    kernel_fn k = kernel_for(h->NL, occ, is_exact(h));
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
     if (e0) HIPCHK(h, hipEventRecord(e0, st));
     // more items than resident wavefronts: hand the walkers out hottest first (see rx_order_bucket)
@@ -565,7 +567,7 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming)) != hipSuccess) return hipfail("hipEventCreate", e);
     { const char *no = getenv("RX_NO_ORDER"); h->issue_order = (no && *no && *no != '0') ? 0 : 1; }   // read once
     int nb = 0;
-    kernel_fn k = kernel_for(h->NL, 2, h->mol.nlev == h->NL);
+    kernel_fn k = kernel_for(h->NL, 2, is_exact(h));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
         h->blocks_per_cu2 = std::min(nb, 2);
     char nm[64];
@@ -1047,7 +1049,7 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     long blocks = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     const long need = (long)((2 * nq * (size_t)nsteps + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK);
     if (blocks > need) blocks = need;
-    sampler_kernel_fn k = sampler_kernel_for(h->NL, occ, h->mol.nlev == h->NL);
+    sampler_kernel_fn k = sampler_kernel_for(h->NL, occ, is_exact(h));
     if (!k) { h->err = "this build has no dataflow sampler kernel"; return RX_E_UNSUPP; }
     fill_args(h, A.k, (int)N, ncomp, RXK_MODE_LNPROB);
     A.s.ens_src = d_ens_src; A.s.coords = d_coords; A.s.lnp = d_lnp; A.s.naccept = d_naccept;
@@ -1080,7 +1082,9 @@ static int peer_launch_shape(rx_handle *h, size_t tasks_per_half_step, size_t to
     long blocks = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     const long need = (long)((total_tasks + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK);
     if (blocks > need) blocks = need;
-    if (h->sampler_grid_limit > 0 && blocks > h->sampler_grid_limit) blocks = h->sampler_grid_limit;
+    // (the limit is in compute units: the two-waves-per-SIMD build places blocks_per_cu2 workgroups on each)
+    const long lim = (long)h->sampler_grid_limit * (occ == 2 ? h->blocks_per_cu2 : 1);
+    if (h->sampler_grid_limit > 0 && blocks > lim) blocks = lim;
     if (blocks < 1) blocks = 1;
     *occ_out = occ; *blocks_out = blocks;
     return 0;
@@ -1219,7 +1223,7 @@ int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, in
     if (!h->h_abort) { HIPCHK(h, hipHostMalloc(&h->h_abort, sizeof(uint32_t))); *h->h_abort = 0; }
     int occ; long blocks;
     peer_launch_shape(h, hi - lo, 2 * (hi - lo) * (size_t)nsteps, &occ, &blocks);
-    sampler_kernel_fn k = sampler_kernel_for(h->NL, occ, h->mol.nlev == h->NL);
+    sampler_kernel_fn k = sampler_kernel_for(h->NL, occ, is_exact(h));
     if (!k) { h->err = "this build has no dataflow sampler kernel"; return RX_E_UNSUPP; }
     fill_args(h, A.k, (int)N, P.ncomp, RXK_MODE_LNPROB);
     A.s.ens_src = d_ens_src;

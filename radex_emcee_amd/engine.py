@@ -307,9 +307,9 @@ class Engine:
     def sampler_peer_close(self):
         self._chk(self._L.rx_sampler_peer_close(self._h), "rx_sampler_peer_close")
 
-    def set_sampler_grid_limit(self, blocks=0):
-        """At most `blocks` workgroups per dataflow launch (0: the whole GPU) -- ranks sharing one GPU."""
-        self._chk(self._L.rx_set_sampler_grid_limit(self._h, int(blocks)), "rx_set_sampler_grid_limit")
+    def set_sampler_grid_limit(self, cus=0):
+        """The peer form's dataflow launches occupy at most `cus` compute units (0: the whole GPU) -- ranks sharing one GPU."""
+        self._chk(self._L.rx_set_sampler_grid_limit(self._h, int(cus)), "rx_set_sampler_grid_limit")
 
     def sampler_stats(self, enable=True):
         """Counters of the dataflow launches since the last call (rx_sampler_stats), then counting on / off."""

@@ -92,8 +92,19 @@ def test_reference_call_site_runs_on_the_device(mol):
     assert isinstance(sampler, DeviceEnsembleSampler)
     state = sampler.run_mcmc(cfg["walkers"], 5, progress=False)
     sampler.reset()
+    # the per-walker functions are pure, like the reference's: called between burn-in and production with OTHER data
+    # they leave the live sampler's source (slot 0 of the process's engine) alone
+    other = np.array([3, 5], dtype=np.int32)
+    ll = likelihood.lnlike(cfg["truth"], other, 2.0 * truth[[2, 3]], 0.3 * truth[[2, 3]], R)
+    assert np.isfinite(ll) and likelihood.model_lvg(other, cfg["truth"], R).shape == (2,)
+    assert np.isfinite(likelihood.lnprob(cfg["truth"], other, truth[[2, 3]], 0.1 * truth[[2, 3]], bounds=bounds))
     sampler.run_mcmc(state, 8, progress=False)
     chain, lnprobability, flatchain = sampler.get_chain(), sampler.get_log_prob(), sampler.get_chain(flat=True)
+    ref = DeviceEnsembleSampler(nwalkers, ndim, engine=R, seed=0)            # the same chain without the interruptions
+    rstate = ref.run_mcmc(cfg["walkers"], 5)
+    ref.reset()
+    ref.run_mcmc(rstate, 8)
+    assert np.array_equal(chain, ref.get_chain()) and np.array_equal(lnprobability, ref.get_log_prob())
     assert chain.shape == (8, 64, 4) and lnprobability.shape == (8, 64) and flatchain.shape == (512, 4)
     # every stored log-probability is what lnprob returns for the stored position
     for w in (0, 17, 63):

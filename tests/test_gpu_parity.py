@@ -59,6 +59,21 @@ def test_lubksb_vs_reference_binary(engines, golden_dir):
         assert np.max(np.abs(x - want) / np.abs(want)) < 1e-10, n
 
 
+def test_lamda_tables_vs_reference_readdata(engines, golden_dir):
+    """Row a6 on the product side: what the library's own LAMDA parser (rx_create) holds for the two committed
+    files equals what the reference binary's readdata_ parsed from them (ref_readdata.json: xnu = E_up - E_low,
+    spfreq, iupp, ilow), bit for bit.  The rate arithmetic of readdata_ is pinned through the oracle
+    (tests/test_oracle_golden.py) and through the matrix_ histories below, whose crate / ctot are the binary's own."""
+    g = json.load(open(os.path.join(golden_dir, "ref_readdata.json")))
+    toy = Engine(os.path.join(golden_dir, "toy6.dat"))
+    for name, eng in (("co_synth", engines[2]), ("toy6", toy)):
+        t = g["molecules"][name]
+        assert (eng.nlev, eng.nline) == (t["nlev"], t["nline"])
+        assert np.array_equal(eng.xnu, np.array(t["xnu"])) and np.array_equal(eng.spfreq, np.array(t["spfreq"]))
+        assert list(eng.iupp) == t["iupp"] and list(eng.ilow) == t["ilow"]
+    toy.close()
+
+
 def test_escprob_vs_reference_binary(engines, golden_dir):
     """The device escprob_ against the 88 values the reference binary's own escprob_ returned
     (sphere / LVG / slab, the branch boundaries, the NaN of the LVG maser branch)."""
