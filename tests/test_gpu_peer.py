@@ -167,7 +167,14 @@ from radex_emcee_amd import workloads
 from radex_emcee_amd.engine import Engine
 from radex_emcee_amd.sampler import DeviceEnsembleSampler, State
 e = Engine(device=0)                                   # every rank on GPU 0: the replicas travel as IPC handles
-if shape == "config2":
+nens, ens_src = 1, None
+if shape == "config3":                                 # three ensembles advanced together, one source slot each
+    c3 = workloads.config3(nw, init="ball"); ncomp = 1; nens = 3; ens_src = np.arange(3)
+    for k in range(3):
+        s3 = c3["sources"][k]
+        e.set_source(s3["tbg"], s3["Jup"], s3["flux"], s3["eflux"], s3["bounds"], src=k)
+    cfg = dict(walkers=c3["walkers"][:3])
+elif shape == "config2":
     cfg = workloads.config2(nw, seed=77); ncomp = 1
     e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
     tf = e.model_flux_batch(cfg["truth"][None, :])[0]
@@ -177,7 +184,7 @@ else:
     e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"], 2, cfg["T_d"])
     tf = e.model_flux_batch(cfg["truth"][None, :])[0]
     e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"], 2, cfg["T_d"])
-d = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5, group=dist.group.WORLD)
+d = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5, group=dist.group.WORLD, nens=nens, ens_src=ens_src)
 d.fallback = False                                     # a timeout is a failure here, not a silent half-step run
 st = d.run_mcmc(cfg["walkers"], nsteps)
 st = d.run_mcmc(st, 3)                                 # a second call: replica re-seeded, step counter continues
@@ -188,7 +195,7 @@ e.close()
 '''
 
 
-@pytest.mark.parametrize("shape,nw,nsteps", [("config2", 1024, 13), ("config4", 256, 4)])
+@pytest.mark.parametrize("shape,nw,nsteps", [("config2", 1024, 13), ("config4", 256, 4), ("config3", 250, 5)])
 def test_peer_dataflow_two_processes_ipc(co_path, mol, tmp_path, shape, nw, nsteps):
     """One process per rank, both on GPU 0, DeviceEnsembleSampler(group=...): the replicas are exported with
     hipIpcGetMemHandle and mapped with hipIpcOpenMemHandle -- the code path of one process per GPU -- and the
@@ -210,8 +217,16 @@ def test_peer_dataflow_two_processes_ipc(co_path, mol, tmp_path, shape, nw, nste
             raise
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     e = Engine(co_path)
-    p0, ncomp = _setup(e, mol, shape, nw)
-    ref = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5)
+    if shape == "config3":                                   # 3 ensembles x 250 walkers: 375 proposals per half-step,
+        c3 = workloads.config3(nw, init="ball")              # blocks of 188 + 187 that cut through the second ensemble
+        for k in range(3):
+            s3 = c3["sources"][k]
+            e.set_source(s3["tbg"], s3["Jup"], s3["flux"], s3["eflux"], s3["bounds"], src=k)
+        p0, ncomp = c3["walkers"][:3], 1
+        ref = DeviceEnsembleSampler(nw, 4, engine=e, seed=5, nens=3, ens_src=np.arange(3))
+    else:
+        p0, ncomp = _setup(e, mol, shape, nw)
+        ref = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5)
     st = ref.run_mcmc(p0, nsteps)
     st = ref.run_mcmc(st, 3)
     for r in range(2):
