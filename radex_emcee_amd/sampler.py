@@ -603,6 +603,7 @@ class DeviceEnsembleSampler:
                 warnings.warn("multi-GPU dataflow sampler unavailable (%s): half-steps + all_gather instead" % err)
             return False
         self.peer_state = True
+        eng._peer_owner = self            # one replica block per handle: another sampler's set-up replaces it
         return True
 
     def _run_peer(self, nsteps, chain, chain_lnp):
@@ -664,6 +665,8 @@ class DeviceEnsembleSampler:
             raise ValueError("The initial log_prob was NaN")
         nsteps = int(nsteps)
         chain = chain_lnp = None
+        if self.peer_state is True and getattr(self.engine, "_peer_owner", None) is not self:
+            self.peer_state = None        # the handle's replica block now belongs to another sampler: set up again
         peer = (self.engine is not None and self._sharded and self.schedule == "dataflow" and not self.time_solves
                 and nsteps > 0 and (self.peer_state is True or (self.peer_state is None and self._peer_setup())))
         if store and nsteps > 0:
