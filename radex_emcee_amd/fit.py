@@ -151,3 +151,55 @@ def fit_source(source, data, ncomp=1, nwalkers=None, n_iter_burn=100, n_iter_wal
     tup = result_tuple(source, z, bounds, Jup, flux, eflux, popt, pcov, pmin, theta_med, chain,
                        lnprobability, T_d=T_d)
     return tup, summarize(flat, ncomp), sampler
+
+
+def fit_all(data, sources=None, ncomp=1, nwalkers=None, n_iter_burn=100, n_iter_walk=None, seed=0, engine=None,
+            warm=True):
+    """The reference's `for source in data.columns:` loop (emcee_radex.py:389-531, emcee_radex_2comp.py:486-611)
+    with the chains of ALL sources advancing together: every source gets its own slot of one engine (tbg, line
+    list, data, prior box[, T_d]), the warm starts run one source after the other like the reference's, and ONE
+    DeviceEnsembleSampler with one ensemble per source runs burn-in and production for all of them in the same
+    persistent kernel (BASELINE configs[2]: 16 sources).  Returns {source: (result tuple, summary)} and the sampler.
+    The ensemble of source number 0 draws the stream a single-source `fit_source(..., sampler="device")` run draws."""
+    from .engine import Engine
+    from .sampler import DeviceEnsembleSampler
+    names = list(data) if sources is None else list(sources)
+    if not 1 <= len(names) <= 60:
+        raise ValueError("between 1 and 60 sources per engine (source slots)")
+    eng = engine or Engine()
+    nwalkers = nwalkers or (100 if ncomp == 1 else 400)
+    n_iter_walk = n_iter_walk or (500 if ncomp == 1 else 1000)
+    ndim = 4 * ncomp
+    rng = np.random.RandomState(seed)
+    meta, pos = [], np.empty((len(names), nwalkers, ndim))
+    for k, name in enumerate(names):
+        if ncomp == 1:
+            z, _lw, Jup, flux, eflux = data_io.get_source(name, data)
+            T_d, p0 = None, P0_1COMP
+        else:
+            z, T_d, _lw, Jup, flux, eflux = data_io.get_source(name, data)
+            p0 = P0_2COMP
+        tbg, bounds = data_io.source_setup(z, ncomp)
+        post = Posterior(Jup, flux, eflux, bounds, tbg, ncomp=ncomp, T_d=T_d, engine=eng, src=k)
+        if warm:
+            popt, pcov, pmin = warm_start(post, p0)
+        else:
+            popt = np.clip(np.asarray(p0, dtype=float), bounds[:, 0], bounds[:, 1])
+            pcov, pmin = None, popt
+        pos[k] = popt + 1e-3 * rng.randn(nwalkers, ndim)                 # emcee_radex.py:477
+        meta.append((name, z, bounds, T_d, Jup, flux, eflux, popt, pcov, pmin))
+    dsm = DeviceEnsembleSampler(nwalkers, ndim, engine=eng, nens=len(names), ens_src=np.arange(len(names)), seed=int(seed))
+    state = dsm.run_mcmc(pos if len(names) > 1 else pos[0], n_iter_burn, store=False)
+    dsm.reset()
+    dsm.run_mcmc(state, n_iter_walk)
+    chain, lnp = dsm.get_chain(), dsm.get_log_prob()
+    if len(names) == 1:
+        chain, lnp = chain[:, None], lnp[:, None]
+    out = {}
+    for k, (name, z, bounds, T_d, Jup, flux, eflux, popt, pcov, pmin) in enumerate(meta):
+        ch, lp = chain[:, k], lnp[:, k]
+        flat = ch.reshape(-1, ndim)
+        theta_med = np.percentile(flat, 50, axis=0)
+        out[name] = (result_tuple(name, z, bounds, Jup, flux, eflux, popt, pcov, pmin, theta_med, ch, lp, T_d=T_d),
+                     summarize(flat, ncomp))
+    return out, dsm

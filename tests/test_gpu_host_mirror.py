@@ -161,3 +161,26 @@ def test_fit_source_end_to_end(tmp_path):
                                        warm=False)                       # default: the sampler on the device
     assert type(smp2).__name__ == "DeviceEnsembleSampler"
     assert len(tup2) == 9 and tup2[3] == 34.0 and tup2[8][0].shape == (3, 32, 8) and len(summ2) == 2
+
+
+def test_fit_all_sources_advance_together():
+    """The reference's loop over the sources of flux.dat with all chains in ONE persistent kernel (fit.fit_all):
+    per-source slots, one ensemble per source; the first source's ensemble is the chain a single-source run draws."""
+    from radex_emcee_amd import data_io, fit
+    data = data_io.read_data()
+    names = list(data)[:5]
+    out, dsm = fit.fit_all(data, sources=names, nwalkers=32, n_iter_burn=4, n_iter_walk=6, seed=3, warm=False)
+    assert list(out) == names and dsm.nens == 5 and dsm.last_schedule == "dataflow"
+    for name in names:
+        tup, summ = out[name]
+        chain, lnp = tup[7]
+        b = tup[2]
+        assert chain.shape == (6, 32, 4) and lnp.shape == (6, 32) and np.all(np.isfinite(lnp))
+        assert np.all(chain >= b[:, 0]) and np.all(chain <= b[:, 1]) and set(summ[0]) == {"n_H2", "T_kin", "N_CO", "P"}
+        # every stored log-probability is the posterior of ITS source at the stored position
+        z, _lw, Jup, flux, eflux = data_io.get_source(name, data)
+        post = fit.Posterior(Jup, flux, eflux, b, data_io.source_setup(z)[0])
+        assert lnp[-1, 7] == post.lnprob(chain[-1, 7])
+    one, _s, _d = fit.fit_source(names[0], data, nwalkers=32, n_iter_burn=4, n_iter_walk=6, seed=3, warm=False,
+                                 sampler="device")
+    assert np.array_equal(one[7][0], out[names[0]][0][7][0])
