@@ -249,7 +249,10 @@ int hip_fail(rx_handle *h, hipError_t e, const char *what)
 
 typedef void (*kernel_fn)(const RxKArgs);
 
-static bool is_exact(const rx_handle *h) { return h->mol.nlev == h->NL; }   // the molecule fills the instantiation: no padding levels
+// the specialised instantiation: the molecule fills it (no padding levels) AND the geometry is LVG, the hot path
+// (emcee/emcee_radex.py:116 escapeProbGeom='lvg'): no geometry branches in its iteration; sphere / slab run the
+// general instantiation of the same size
+static bool is_exact(const rx_handle *h) { return h->mol.nlev == h->NL && h->method == 2; }
 typedef void (*lukernel_fn)(const double *, double *, int32_t *, int, int);
 
 lukernel_fn lukernel_for(int NL)
