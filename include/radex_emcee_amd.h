@@ -201,7 +201,9 @@ int rx_set_sampler_timeout_ms(rx_handle *h, double ms);
  * transport): after rx_sampler_peer_begin on every rank (no peer may write into a replica that is still being
  * seeded) and after rx_sampler_wait on every rank (a replica is complete only when every peer has finished).
  *   rx_sampler_peer_setup    allocates this rank's replica for (nens, nwalkers, ncomp) and exports it:
- *                            ipc_handle_out[RX_IPC_HANDLE_BYTES] (hipIpcGetMemHandle), may be NULL
+ *                            ipc_handle_out[RX_IPC_HANDLE_BYTES] (hipIpcGetMemHandle), may be NULL; the environment
+ *                            variable RX_NO_PEER=1 makes it fail with RX_E_UNSUPP (callers then use the half-step
+ *                            schedule: the way to rehearse that fall-back)
  *   rx_sampler_peer_base     the replica as a device pointer (peers inside ONE process: two handles, tests)
  *   rx_sampler_peer_connect  ipc_handles: [nranks][RX_IPC_HANDLE_BYTES], every rank's handle in rank order
  *                            (own entry ignored), or bases: [nranks] device pointers valid in this process

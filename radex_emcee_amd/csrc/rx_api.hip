@@ -1121,6 +1121,7 @@ int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwal
     rxs::StretchArgs probe;
     { int rc = stretch_args(h, probe, nens, nwalkers, 4 * ncomp, 2.0, 0, 0, 0); if (rc) return rc; }
     if (ncomp != 1 && ncomp != 2) { h->err = "ncomp must be 1 or 2"; return RX_E_ARG; }
+    { const char *off = getenv("RX_NO_PEER"); if (off && *off && *off != '0') { h->err = "peer replicas switched off (RX_NO_PEER)"; return RX_E_UNSUPP; } }
     (void)rx_sampler_peer_close(h);
     HIPCHK(h, hipSetDevice(h->device));
     rx_handle::Peer &P = h->peer;

@@ -236,3 +236,29 @@ def test_peer_dataflow_two_processes_ipc(co_path, mol, tmp_path, shape, nw, nste
         assert np.array_equal(z["chain"], ref.get_chain()) and np.array_equal(z["chain_lnp"], ref.get_log_prob())
         assert np.array_equal(z["acc"], ref.acceptance_fraction)
     e.close()
+
+
+@pytest.mark.parametrize("failing", [(0, 1), (1,)])
+def test_peer_unavailable_falls_back_to_halfsteps_on_every_rank(co_path, mol, tmp_path, failing):
+    """When the replicas cannot be set up (here: switched off with RX_NO_PEER=1 on both ranks or on ONE of them, as a
+    failing hipExtMallocWithFlags / hipIpcGetMemHandle would on a real node) the ranks agree on it and run the
+    half-step schedule with the all-gather: the same chain, no hang."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "peer_worker.py"
+    script.write_text(WORKER)
+    envs = [dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RX_NO_PEER="1" if r in failing else "0") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-W", "ignore", str(script), ROOT, str(r), "2", str(port), str(tmp_path), "config2",
+                               "256", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=envs[r]) for r in range(2)]
+    outs = [p.communicate(timeout=420)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    e = Engine(co_path)
+    p0, ncomp = _setup(e, mol, "config2", 256)
+    ref = DeviceEnsembleSampler(256, 4, engine=e, seed=5)
+    st = ref.run_mcmc(p0, 4)
+    st = ref.run_mcmc(st, 3)
+    for r in range(2):
+        z = np.load(tmp_path / ("peer_%d.npz" % r))
+        assert str(z["schedule"]) == "halfsteps" and "RX_NO_PEER" in str(z["peer"])
+        assert np.array_equal(z["coords"], st.coords) and np.array_equal(z["chain"], ref.get_chain())
+    e.close()
