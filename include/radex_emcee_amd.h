@@ -114,6 +114,13 @@ int rx_set_source(rx_handle *h, int src, double tbg, int nJ, const int32_t *Jup,
  * short-circuit); enabled = 1 restores lnprob.  rx_set_source re-enables the prior.          */
 int rx_set_source_prior(rx_handle *h, int src, int enabled);
 
+/* Replaces lnprior(p, bounds[, T_d]) on its own (emcee/emcee_radex.py:169-175,
+ * emcee/emcee_radex_2comp.py:199-234): the box, the ordering constraints and, for two components,
+ * the flat/Gaussian terms of slot `src` (bounds, ncomp and T_d as given to rx_set_source) for N
+ * host-side parameter vectors [N][4*ncomp]; no solve is run.  The same device function as the
+ * fused prior of rx_lnprob_batch*.                                                            */
+int rx_lnprior_batch(rx_handle *h, int src, int N, const double *params, double *lnprior_out);
+
 /* Replaces lnprob(p, Jup, flux, eflux, bounds[, T_d]) called once per walker
  * through pool.map (emcee/emcee_radex.py:177-181,
  * emcee/emcee_radex_2comp.py:237-244) by ONE launch over N walkers.

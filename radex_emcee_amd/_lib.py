@@ -28,7 +28,7 @@ EXPORTS = [
     "rx_set_sampler_timeout_ms", "rx_set_waves_per_simd",
     "rx_sampler_peer_setup", "rx_sampler_peer_base", "rx_sampler_peer_connect", "rx_sampler_peer_begin",
     "rx_sampler_peer_run", "rx_sampler_peer_finish", "rx_sampler_peer_close", "rx_set_sampler_grid_limit",
-    "rx_sampler_stats",
+    "rx_sampler_stats", "rx_lnprior_batch",
 ]
 ABI_VERSION = 3
 RX_MAX_RANKS = 8
@@ -106,6 +106,7 @@ def load():
     L.rx_set_issue_order.argtypes = [vp, C.c_int]
     L.rx_set_waves_per_simd.argtypes = [vp, C.c_int]
     L.rx_set_source_prior.argtypes = [vp, C.c_int, C.c_int]
+    L.rx_lnprior_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     u64, i64 = C.c_uint64, C.c_int64
     L.rx_stretch_propose_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, u64, i64, C.c_int,
                                             vp, vp, vp, vp, vp, vp, vp]

@@ -776,6 +776,27 @@ int rx_lnprob_batch(rx_handle *h, int N, const double *params, const int32_t *sr
     return 0;
 }
 
+int rx_lnprior_batch(rx_handle *h, int src, int N, const double *params, double *lnprior_out)
+{
+    if (!h || N < 0 || (N > 0 && (!params || !lnprior_out))) return RX_E_ARG;
+    if (N == 0) return 0;
+    int ncomp = 0;
+    { int rc = source_ncomp(h, nullptr, N, src, &ncomp); if (rc) return rc; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t np = (size_t)N * 4 * ncomp;
+    HIPCHK(h, h->s_params.reserve(np));
+    HIPCHK(h, h->s_lnp.reserve(N));
+    hipStream_t st = nullptr;
+    { int rc = order_after_last(h, st); if (rc) return rc; }
+    HIPCHK(h, hipMemcpyAsync(h->s_params.p, params, np * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rxk::rx_lnprior_kernel, dim3((N + 255) / 256), dim3(256), 0, st,
+                       (const RxSourceDev *)h->d_srcs, src, ncomp, (const double *)h->s_params.p, h->s_lnp.p, N);
+    HIPCHK(h, hipGetLastError());
+    { int rc = mark_launched(h, st); if (rc) return rc; }
+    HIPCHK(h, hipMemcpy(lnprior_out, h->s_lnp.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int rx_model_flux_batch_device(rx_handle *h, int src, int N, const double *d_params, double *d_flux_out,
                                int32_t *d_status, int32_t *d_niter, void *stream)
 {

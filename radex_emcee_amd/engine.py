@@ -110,6 +110,17 @@ class Engine:
         self._chk(self._L.rx_set_source_prior(self._h, int(src), 1 if enabled else 0), "rx_set_source_prior")
 
     # -- batched evaluation, host buffers --------------------------------------------
+    def lnprior_batch(self, params, src=0):
+        """lnprior of slot `src` alone for [N, 4*ncomp] parameter vectors (rx_lnprior_batch; no solve)."""
+        if int(src) not in self._sources:
+            raise EngineError("source slot %d not set" % int(src))
+        ncomp = self._sources[int(src)]["ncomp"]
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4 * ncomp)
+        out = np.empty(params.shape[0])
+        self._chk(self._L.rx_lnprior_batch(self._h, int(src), params.shape[0], _dp(params), _dp(out)),
+                  "rx_lnprior_batch")
+        return out
+
     def lnprob_batch(self, params, src_index=None, return_info=False):
         si = None if src_index is None else np.ascontiguousarray(src_index, dtype=np.int32).ravel()
         # the batch layout follows the sources the batch addresses (the library checks they all agree)

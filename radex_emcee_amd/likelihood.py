@@ -8,8 +8,7 @@ and the batched form the sampler uses (one kernel launch per half-step):
     Posterior(...).lnprob_batch(P[N, ndim]) -> lnp[N]
 
 All numerics (prior, RADEX solve, chi^2) run in libradex_emcee_amd.so; these functions only
-marshal arguments.  `lnprior` is also available as pure host logic for bound checking in
-optimiser warm-starts.
+marshal arguments.
 """
 from __future__ import annotations
 
@@ -89,32 +88,17 @@ def model_lvg(Jup, params, R=None):
 
 
 def lnprior(p, bounds, T_d=None, R=None):
-    """emcee_radex.py:169-175; emcee_radex_2comp.py:199-234 (host logic, no engine needed)."""
+    """emcee_radex.py:169-175; emcee_radex_2comp.py:199-234.  Evaluated by the engine's own prior
+    (rx_lnprior_batch: the device function the fused lnprob uses; no solve is run): no second
+    statement of the branches on the host."""
+    R = R or globals()["R"]
+    if R is None:
+        raise RuntimeError("call init_radex() first (the prior is evaluated by the engine)")
     p = np.asarray(p, dtype=np.float64)
-    bounds = np.asarray(bounds, dtype=np.float64)
-    if np.any(p > bounds[:, 1]) or np.any(p < bounds[:, 0]):
-        return -np.inf
-    if p.size == 4:
-        if (p[2] - p[0] >= 17.5) or (p[2] - p[0] <= 10.0):
-            return -np.inf
-        return 0.0
-    if p[5] <= p[1]:
-        return -np.inf
-    if ((p[2] - p[0]) >= 18.0 or (p[2] - p[0]) <= 9.0 or (p[6] - p[4]) >= 18.0 or (p[6] - p[4]) <= 9.0):
-        return -np.inf
-    if p[3] < p[7]:
-        return -np.inf
-    logp = 0.0
-    for idx, (value, bound) in enumerate(zip(p, bounds)):
-        if idx == 1 and T_d is not None:
-            T_kin = 10.0 ** value
-            if T_d <= 0:
-                return -np.inf
-            sigma = 1.0 * T_d
-            logp += (-0.5 * ((T_kin - T_d) / sigma) ** 2.0 - np.log(sigma * np.sqrt(2.0 * np.pi)))
-        else:
-            logp += -(bound[1] - bound[0])
-    return logp
+    ncomp = p.size // 4
+    one = np.ones(1)
+    R.set_source(getattr(R, "_tbg", 2.7315), np.array([1]), one, one, bounds, ncomp, T_d, src=_SLOT_SCRATCH)
+    return float(R.lnprior_batch(p[None, :], src=_SLOT_SCRATCH)[0])
 
 
 def lnlike(p, Jup, flux, eflux, R=None, sigma_floor=1e-12):

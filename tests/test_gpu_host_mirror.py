@@ -184,3 +184,41 @@ def test_fit_all_sources_advance_together():
     one, _s, _d = fit.fit_source(names[0], data, nwalkers=32, n_iter_burn=4, n_iter_walk=6, seed=3, warm=False,
                                  sampler="device")
     assert np.array_equal(one[7][0], out[names[0]][0][7][0])
+
+
+def test_lnprior_alone_is_the_engines_prior(mol):
+    """likelihood.lnprior (emcee_radex.py:169-175, emcee_radex_2comp.py:199-234) is rx_lnprior_batch: the
+    same edge cases as the oracle's own tests (tests/test_host_logic.py), against the oracle."""
+    from radex_emcee_amd import workloads
+    likelihood.R = None
+    likelihood.init_radex(2.7315 * 3.5)
+    z = 2.5
+    b = workloads.bounds_1comp(z)
+    Jup = np.array([1, 3], dtype=np.int32)
+    src = O.Source(2.7315 * (1 + z), Jup, np.ones(2), np.ones(2), b)
+    mid = [4.0, 1.8, 17.0, 0.5 * (b[3, 0] + b[3, 1])]
+    cases = [mid, [b[0, 0], 1.8, 15.5, mid[3]], [6.0, 1.8, 16.0, mid[3]], [2.0, 1.8, 19.5, mid[3]],
+             [2.0, 1.8, 19.4999, mid[3]], [4.0, 1.8, float("nan"), mid[3]]]
+    for k in range(4):
+        for edge, eps in ((1, 1e-12), (0, -1e-12)):
+            p = list(mid); p[k] = b[k, edge] + eps
+            cases.append(p)
+    for p in cases:
+        assert likelihood.lnprior(p, b) == O.lnprior(src, p), p
+    b2 = workloads.bounds_2comp(z)
+    p = np.array([1.9, 1.2, 16.4, -12.1, 3.9, 2.5, 17.5, -12.1])
+    variants = [p]
+    for k, v in ((5, p[1]), (3, p[7] - 1e-9), (3, p[7]), (2, p[0] + 9.0), (6, p[4] + 18.0), (0, b2[0, 1] + 1e-9)):
+        q = p.copy(); q[k] = v
+        variants.append(q)
+    for T_d in (40.0, None, 0.0):
+        src2 = O.Source(2.7315 * (1 + z), Jup, np.ones(2), np.ones(2), b2, 2, T_d)
+        for q in variants:
+            want = O.lnprior(src2, q)
+            got = likelihood.lnprior(q, b2, T_d)
+            assert (got == want) or got == pytest.approx(want, rel=1e-14), (T_d, q)
+    # a batch in one call
+    P = np.array(cases)
+    likelihood.R.set_source(2.7315 * 3.5, Jup, np.ones(2), np.ones(2), b, 1, None, src=5)
+    got = likelihood.R.lnprior_batch(P, src=5)
+    assert np.array_equal(got, [O.lnprior(src, q) for q in cases])
