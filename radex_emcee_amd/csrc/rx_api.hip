@@ -308,6 +308,8 @@ int build_tables(rx_handle *h)
     for (const Partner &P : m.parts) if (P.id == 1) h->h2_total = 1;
 
     RxLevTab LV;
+    for (int q = 0; q < RXK_MAXPART; ++q) { LV.p_temps[q] = nullptr; LV.p_ksym[q] = nullptr; LV.p_ntemp[q] = 0; }
+    LV.pad_ = 0;
     for (int i = 0; i < RXK_MAXLEV; ++i) { LV.eterm[i] = 0.0; LV.gstat[i] = 1.0; LV.rgstat[i] = 1.0; }
     for (int i = 0; i < m.nlev; ++i) { LV.eterm[i] = m.eterm[i]; LV.gstat[i] = m.gstat[i]; LV.rgstat[i] = 1.0 / m.gstat[i]; }
     RxLineTab LT;
@@ -385,6 +387,9 @@ int build_tables(rx_handle *h)
         h->d_ksym.push_back(dK);
         D.ksym[q] = dK;
     }
+    // the partner table inside the level table (what the kernels read from LDS), now that the addresses exist
+    for (size_t q = 0; q < h->order.size(); ++q) { LV.p_temps[q] = D.temps[q]; LV.p_ksym[q] = D.ksym[q]; LV.p_ntemp[q] = D.ntemp[q]; }
+    HIPCHK(h, hipMemcpy(base + off_e, &LV, sizeof LV, hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -42,6 +42,13 @@ struct RxLevTab {
     double eterm[RXK_MAXLEV];       // cm^-1 (padding levels: 0)
     double gstat[RXK_MAXLEV];       // (padding levels: 1)
     double rgstat[RXK_MAXLEV];      // 1/gstat, correctly rounded on the host (the device divides through it)
+    // The collision partners again (the values of RxMolDev below): a kernel stages this table in LDS and reads
+    // them there with a run-time partner index -- indexing the kernel-argument copy is a memory round trip per
+    // field, five per partner and walker.
+    const double *p_temps[RXK_MAXPART];
+    const double *p_ksym[RXK_MAXPART];
+    int32_t p_ntemp[RXK_MAXPART];
+    int32_t pad_;
 };
 
 struct RxMolDev {

@@ -4,9 +4,10 @@ sys.path.insert(0, ".")
 import numpy as np
 from radex_emcee_amd.engine import Engine
 from radex_emcee_amd import workloads
-cfg = workloads.config2(1024); e = Engine(); e.set_source(cfg["tbg"]); W = cfg["walkers"]; n = 10 ** W[:, 0]
+N = int(os.environ.get("RX_STAMP_N", "1024"))        # fewer walkers = fewer wavefronts starting in lock step
+cfg = workloads.config2(N); e = Engine(); e.set_source(cfg["tbg"]); W = cfg["walkers"]; n = 10 ** W[:, 0]
 r = e.solve_batch(10 ** W[:, 1], 10 ** W[:, 2], np.stack([0.25 * n, 0.75 * n], 1))
-d = np.fromfile("/tmp/stamps.bin").reshape(1024, 64)
+d = np.fromfile("/tmp/stamps.bin").reshape(-1, 64)[:N]
 slots = [int(x) for x in sys.argv[2].split(",")]
 ok = np.all(np.isfinite(d[:, slots]), axis=1) & (d[:, slots[-1]] > d[:, slots[0]])
 if len(sys.argv) > 3 and sys.argv[3] == "slow":       # only the walkers that run into maxiter (they set the launch time)
