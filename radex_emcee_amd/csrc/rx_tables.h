@@ -9,7 +9,9 @@
 #define RXK_MAXNJ 32
 #define RXK_MAXSRC 64
 #define RXK_ORDER_BUCKETS 32
+#ifndef RXK_WAVES_PER_BLOCK
 #define RXK_WAVES_PER_BLOCK 4  // one workgroup = 4 wavefronts = 4 walkers in flight, 1 per SIMD
+#endif
 
 // Per-line constants.  Everything here is a pure function of the molecular
 // data file, evaluated on the host with the same operand order the reference
