@@ -539,7 +539,11 @@ def main():
                         "maxiter_fraction": round(stt["maxiter_solves"] / solved, 5),
                         "mean_task_us": round(task_us, 2), "mean_wait_for_inputs_us": round(stt["wait_ticks"] / tasks / 100.0, 2),
                         "dependency_floor_ms_per_step": round(floor_ms, 4),
-                        "fraction_of_dependency_floor": round(floor_ms / ms_step, 4)}
+                        "fraction_of_dependency_floor": round(floor_ms / ms_step, 4),
+                        # rx_set_sampler_speculation: tasks that started before their partner was final, and of those
+                        # the ones whose hypotheses were both wrong (evaluated once more from the real position)
+                        "tasks_with_a_head_start": round(stt.get("head_starts", 0) / tasks, 4),
+                        "tasks_evaluated_again": round(stt.get("evaluated_twice", 0) / tasks, 4)}
 
             dsm = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)       # schedule="dataflow"
             sd = dsm.run_mcmc(p0, 20, store=False)                       # a short burn-in
@@ -559,7 +563,7 @@ def main():
             nsp = 120
             eng.sampler_stats(True)
             ts = time.perf_counter()
-            dsp.run_mcmc(State(sp.coords, sp.log_prob), nsp, store=False)
+            spf = dsp.run_mcmc(State(sp.coords, sp.log_prob), nsp, store=False)
             torch.cuda.synchronize()
             tsp = time.perf_counter() - ts
             out["sampler_config2_prior_box"] = dict(
@@ -569,7 +573,20 @@ def main():
                  "walker_steps_per_s": round(nw * nsp / tsp, 1), "unit": "walker-steps/s = lnlike evaluations/s",
                  "acceptance": round(float(dsp.acceptance_fraction.mean()), 3)},
                 **stats_fields(eng.sampler_stats(False), nsp, tsp / nsp * 1e3))
-            del dsp
+            # the same 140 steps with every task waiting for its partner (round 2's schedule): the same chain, slower
+            eng.set_sampler_speculation(0)
+            dsq = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)
+            sq = dsq.run_mcmc(cfg["walkers"], 20, store=False)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            sq = dsq.run_mcmc(State(sq.coords, sq.log_prob), nsp, store=False)
+            torch.cuda.synchronize()
+            tsq = time.perf_counter() - ts
+            eng.set_sampler_speculation(-1)
+            out["sampler_config2_prior_box"]["without_head_starts"] = {
+                "ms_per_step": round(tsq / nsp * 1e3, 4), "walker_steps_per_s": round(nw * nsp / tsq, 1),
+                "same_chain": bool(np.array_equal(sq.coords, spf.coords) and np.array_equal(sq.log_prob, spf.log_prob))}
+            del dsp, dsq
             # the same 100 steps again under the half-step schedule (identical proposals), then once more with
             # HIP events around every solve launch: the mean kernel time of THIS chain's half-steps (a
             # half-step lasts as long as its slowest proposal, which varies from one half-step to the next)

@@ -242,6 +242,18 @@ int rx_set_sampler_grid_limit(rx_handle *h, int cus);
  * maxiter, [4] 100 MHz wall-clock ticks summed over the tasks between "inputs final" and "result published",
  * [5] ticks summed over the tasks between "dequeued" and "inputs final" (polling).                     */
 int rx_sampler_stats(rx_handle *h, int enable, uint64_t *out6);
+/* The dataflow sampler's head start (both forms, one GPU and peers).  A task whose partner's LAST update is still
+ * pending starts on the partner's previous position instead of sleeping; a stretch move is rejected more often
+ * than not, and a rejected update leaves the position as it was.  When the partner's version arrives the two
+ * positions are compared bit for bit: equal, the result stands; different, the task is evaluated again from the
+ * right position.  The chain is the same chain, bit for bit; only idle time is spent.
+ *   mode  -1 (default) and 1: on; 0: off.  The head start exists for launches that run one wavefront per SIMD
+ *         (the latency regime: up to 1536 tasks per half-step on 256 CUs, idle wavefronts); where two wavefronts
+ *         share a SIMD a wasted evaluation slows its neighbour down, and the mode is ignored (measured 2-4 % slower).
+ * rx_sampler_spec_stats: out2[0] tasks that took the head start, out2[1] of those, tasks evaluated twice --
+ * as counted up to the most recent rx_sampler_stats call that read the counters.                              */
+int rx_set_sampler_speculation(rx_handle *h, int mode);
+int rx_sampler_spec_stats(rx_handle *h, uint64_t *out2);
 int rx_stretch_propose_device(rx_handle *h, int nens, int nwalkers, int ndim, double a,
                               uint64_t seed, int64_t step, int split,
                               const int32_t *d_ens_src, const double *d_coords, double *d_q,

@@ -28,7 +28,7 @@ EXPORTS = [
     "rx_set_sampler_timeout_ms", "rx_set_waves_per_simd",
     "rx_sampler_peer_setup", "rx_sampler_peer_base", "rx_sampler_peer_connect", "rx_sampler_peer_begin",
     "rx_sampler_peer_run", "rx_sampler_peer_finish", "rx_sampler_peer_close", "rx_set_sampler_grid_limit",
-    "rx_sampler_stats", "rx_lnprior_batch",
+    "rx_sampler_stats", "rx_lnprior_batch", "rx_set_sampler_speculation", "rx_sampler_spec_stats",
 ]
 ABI_VERSION = 3
 RX_MAX_RANKS = 8
@@ -134,6 +134,8 @@ def load():
     L.rx_sampler_peer_close.argtypes = [vp]
     L.rx_set_sampler_grid_limit.argtypes = [vp, C.c_int]
     L.rx_sampler_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+    L.rx_sampler_spec_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rx_set_sampler_speculation.argtypes = [vp, C.c_int]
     L.rx_time_lnprob_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
     if L.rx_abi_version() != ABI_VERSION:
         raise EngineLibraryMissing("%s has ABI version %d, this package needs %d: rebuild it"

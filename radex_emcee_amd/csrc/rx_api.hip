@@ -206,12 +206,16 @@ struct rx_handle {
     // dataflow sampler (rx_sampler_run_async_device): per-walker version counters, abort flag
     DevBuf<uint32_t> w_version;      // [N] version counters, then [RING] per-step counters
     DevBuf<double> w_hist;           // [RING][N][ndim] positions by version
+    DevBuf<double> w_pend;           // [N][ndim] proposals of the tasks in flight (the dataflow sampler's second hypothesis)
+    DevBuf<uint32_t> w_pendver;      // [N]
     uint32_t *d_abort = nullptr;
     uint32_t *h_abort = nullptr;     // pinned mirror, filled by an async copy behind every async run
     long long sampler_timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock: far beyond any real wait
     int sampler_grid_limit = 0;      // > 0: the dataflow launches of the peer form occupy at most this many CUs (ranks sharing one GPU)
     unsigned long long *d_stats = nullptr;   // [8] counters of the dataflow launches since the last rx_sampler_stats
     int stats_on = 0;
+    unsigned long long last_spec[2] = {0, 0};   // counters [6], [7] as read by the last rx_sampler_stats
+    int speculation = -1;            // dataflow sampler: -1 = on where one wavefront runs per SIMD, 0 = off, 1 = on (rx_set_sampler_speculation)
     // multi-GPU dataflow sampler (rx_sampler_peer_*): this rank's replica block and the peers' blocks as mapped here
     struct Peer {
         int nranks = 0, rank = 0, nens = 0, nwalkers = 0, ncomp = 0, nsteps_run = 0;
@@ -604,7 +608,7 @@ void rx_destroy(rx_handle *h)
     h->s_niter.release(); h->s_cstatus.release(); h->s_cniter.release(); h->s_srcfix.release();
     h->s_order.release();
     h->w_q.release(); h->w_factor.release(); h->w_lnpq.release(); h->w_widx.release();
-    h->w_qsrc.release(); h->w_qstatus.release(); h->w_qniter.release(); h->w_version.release(); h->w_hist.release();
+    h->w_qsrc.release(); h->w_qstatus.release(); h->w_qniter.release(); h->w_version.release(); h->w_hist.release(); h->w_pend.release(); h->w_pendver.release();
     if (h->d_abort) (void)hipFree(h->d_abort);
     if (h->d_stats) (void)hipFree(h->d_stats);
     (void)rx_sampler_peer_close(h);
@@ -1067,6 +1071,8 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     constexpr int RING = 12;                         // versions of the positions kept readable (see the kernel)
     HIPCHK(h, h->w_version.reserve(N + RING));
     HIPCHK(h, h->w_hist.reserve((size_t)RING * N * ndim));
+    HIPCHK(h, h->w_pend.reserve(N * ndim));
+    HIPCHK(h, h->w_pendver.reserve(N));
     if (!h->d_abort) { HIPCHK(h, hipMalloc(&h->d_abort, sizeof(uint32_t))); HIPCHK(h, hipMemset(h->d_abort, 0, sizeof(uint32_t))); }
     if (!h->h_abort) { HIPCHK(h, hipHostMalloc(&h->h_abort, sizeof(uint32_t))); *h->h_abort = 0; }
     // few tasks per half-step: one wavefront per SIMD (lowest latency per task), the whole chip so that
@@ -1088,10 +1094,13 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     A.chain = d_chain; A.chain_lnp = d_chain_lnp;
     A.timeout_ticks = h->sampler_timeout_ticks;
     A.stats = h->stats_on ? h->d_stats : nullptr;
+    A.speculate = (occ == 1) && h->speculation != 0;        // (the head start exists in the one-wavefront-per-SIMD build only)
+    if (A.speculate) { A.pend = h->w_pend.p; A.pend_version = h->w_pendver.p; }    // (proposals are published only for head starts)
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
     // (the abort word is STICKY: raised by a run, it stays up -- and ends every later run at its first wait --
     // until rx_sampler_wait has reported it; a second run enqueued before the wait cannot lose it)
     HIPCHK(h, hipMemsetAsync(h->w_version.p, 0, (N + RING) * sizeof(uint32_t), st));
+    HIPCHK(h, hipMemsetAsync(h->w_pendver.p, 0, N * sizeof(uint32_t), st));
     HIPCHK(h, hipMemcpyAsync(h->w_hist.p, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));   // version 0
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, A);
     HIPCHK(h, hipGetLastError());
@@ -1269,6 +1278,7 @@ int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, in
     A.chain = d_chain; A.chain_lnp = d_chain_lnp;
     A.timeout_ticks = h->sampler_timeout_ticks;
     A.stats = h->stats_on ? h->d_stats : nullptr;
+    A.speculate = (occ == 1) && h->speculation != 0;
     // (nranks = 1 runs the very same kernel in its one-GPU form on the replica block)
     A.nranks = P.nranks; A.rank = P.rank; A.t_lo = (uint32_t)lo; A.t_n = (uint32_t)(hi - lo);
     A.peers = P.d_bases;
@@ -1314,9 +1324,24 @@ int rx_sampler_stats(rx_handle *h, int enable, uint64_t *out6)
         unsigned long long v[8];
         HIPCHK(h, hipMemcpy(v, h->d_stats, sizeof v, hipMemcpyDeviceToHost));
         for (int i = 0; i < 6; ++i) out6[i] = v[i];
+        h->last_spec[0] = v[6]; h->last_spec[1] = v[7];
     }
     HIPCHK(h, hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long)));
     h->stats_on = enable ? 1 : 0;
+    return 0;
+}
+
+int rx_sampler_spec_stats(rx_handle *h, uint64_t *out2)
+{
+    if (!h || !out2) return RX_E_ARG;
+    out2[0] = h->last_spec[0]; out2[1] = h->last_spec[1];
+    return 0;
+}
+
+int rx_set_sampler_speculation(rx_handle *h, int mode)
+{
+    if (!h || mode < -1 || mode > 1) return RX_E_ARG;
+    h->speculation = mode;
     return 0;
 }
 

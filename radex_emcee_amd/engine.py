@@ -328,7 +328,15 @@ class Engine:
         self._chk(self._L.rx_sampler_stats(self._h, 1 if enable else 0, v), "rx_sampler_stats")
         t = dict(tasks=int(v[0]), solved=int(v[1]), niter_sum=int(v[2]), maxiter_solves=int(v[3]),
                  busy_ticks=int(v[4]), wait_ticks=int(v[5]))
+        w = (C.c_uint64 * 2)()
+        self._chk(self._L.rx_sampler_spec_stats(self._h, w), "rx_sampler_spec_stats")
+        t.update(head_starts=int(w[0]), evaluated_twice=int(w[1]))      # (rx_set_sampler_speculation)
         return t
+
+    def set_sampler_speculation(self, mode=-1):
+        """The dataflow sampler's head start on the partner's previous position: -1 = automatic (on where one
+        wavefront runs per SIMD), 0 = off, 1 = on.  The chain is the same either way (rx_set_sampler_speculation)."""
+        self._chk(self._L.rx_set_sampler_speculation(self._h, int(mode)), "rx_set_sampler_speculation")
 
     def set_sampler_timeout_ms(self, ms):
         self._chk(self._L.rx_set_sampler_timeout_ms(self._h, float(ms)), "rx_set_sampler_timeout_ms")

@@ -16,6 +16,7 @@ eng = Engine()
 eng.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
 tf = eng.model_flux_batch(cfg["truth"][None, :])[0]
 eng.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"])
+if os.environ.get("RX_SPECULATE"): eng.set_sampler_speculation(int(os.environ["RX_SPECULATE"]))
 d = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)
 s = d.run_mcmc(cfg["walkers"], 20, store=False)
 torch.cuda.synchronize()
@@ -28,4 +29,5 @@ st = eng.sampler_stats(False)
 print(json.dumps({"walkers": nw, "steps": nst, "ms_per_step": dt / nst * 1e3, "walker_steps_per_s": nw * nst / dt,
                   "niter_mean": st["niter_sum"] / max(1, st["solved"]), "maxiter_fraction": st["maxiter_solves"] / max(1, st["solved"]),
                   "outside_prior": 1 - st["solved"] / max(1, st["tasks"]), "mean_task_us": st["busy_ticks"] / max(1, st["tasks"]) / 100.0,
-                  "mean_wait_us": st["wait_ticks"] / max(1, st["tasks"]) / 100.0}))
+                  "mean_wait_us": st["wait_ticks"] / max(1, st["tasks"]) / 100.0,
+                  "head_starts": st["head_starts"] / max(1, st["tasks"]), "evaluated_twice": st["evaluated_twice"] / max(1, st["tasks"])}))
