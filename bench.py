@@ -533,7 +533,10 @@ def main():
             def stats_fields(stt, nst_, ms_step):
                 tasks, solved = max(1, stt["tasks"]), max(1, stt["solved"])
                 task_us = stt["busy_ticks"] / tasks / 100.0               # 100 MHz wall clock
-                floor_ms = 2.0 * task_us * 1e-3                            # a walker's own chain: two dependent tasks per step
+                # a walker's own chain WITHOUT head starts: its task of this step after its task of the last one, after its
+                # partner's (two dependent evaluations per step).  With head starts (rx_set_sampler_speculation) a task no
+                # longer waits for a rejected update of its own walker, and a step can be shorter than this.
+                floor_ms = 2.0 * task_us * 1e-3
                 return {"tasks": stt["tasks"], "proposals_outside_the_prior": round(1.0 - stt["solved"] / tasks, 4),
                         "niter_mean": round(stt["niter_sum"] / solved, 2),
                         "maxiter_fraction": round(stt["maxiter_solves"] / solved, 5),

@@ -52,7 +52,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     pb = d["sampler_config2_prior_box"]
     assert pb["steps"] >= 100 and pb["burn_in_steps"] == 20 and pb["walker_steps_per_s"] > 0
     assert pb["tasks"] == 1024 * pb["steps"] and 10.0 <= pb["niter_mean"] <= 200.0 and 0.0 <= pb["maxiter_fraction"] < 0.5
-    assert 0.0 < pb["fraction_of_dependency_floor"] <= 1.05
+    assert 0.0 < pb["fraction_of_dependency_floor"] <= 2.0          # (two dependent evaluations per step; head starts can beat it)
     assert 0.0 < pb["tasks_with_a_head_start"] < 1.0 and pb["tasks_evaluated_again"] < pb["tasks_with_a_head_start"]
     assert pb["without_head_starts"]["same_chain"] is True and pb["without_head_starts"]["ms_per_step"] > 0
     c0 = d["config0"]
