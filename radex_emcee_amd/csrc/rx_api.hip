@@ -1071,8 +1071,8 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     constexpr int RING = 12;                         // versions of the positions kept readable (see the kernel)
     HIPCHK(h, h->w_version.reserve(N + RING));
     HIPCHK(h, h->w_hist.reserve((size_t)RING * N * ndim));
-    HIPCHK(h, h->w_pend.reserve(2 * N * ndim));
-    HIPCHK(h, h->w_pendver.reserve(2 * N));
+    HIPCHK(h, h->w_pend.reserve((size_t)rxs::PEND_SLOTS * N * ndim));
+    HIPCHK(h, h->w_pendver.reserve((size_t)rxs::PEND_SLOTS * N));
     if (!h->d_abort) { HIPCHK(h, hipMalloc(&h->d_abort, sizeof(uint32_t))); HIPCHK(h, hipMemset(h->d_abort, 0, sizeof(uint32_t))); }
     if (!h->h_abort) { HIPCHK(h, hipHostMalloc(&h->h_abort, sizeof(uint32_t))); *h->h_abort = 0; }
     // few tasks per half-step: one wavefront per SIMD (lowest latency per task), the whole chip so that
@@ -1100,7 +1100,7 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     // (the abort word is STICKY: raised by a run, it stays up -- and ends every later run at its first wait --
     // until rx_sampler_wait has reported it; a second run enqueued before the wait cannot lose it)
     HIPCHK(h, hipMemsetAsync(h->w_version.p, 0, (N + RING) * sizeof(uint32_t), st));
-    HIPCHK(h, hipMemsetAsync(h->w_pendver.p, 0, 2 * N * sizeof(uint32_t), st));
+    HIPCHK(h, hipMemsetAsync(h->w_pendver.p, 0, (size_t)rxs::PEND_SLOTS * N * sizeof(uint32_t), st));
     HIPCHK(h, hipMemcpyAsync(h->w_hist.p, d_coords, N * ndim * sizeof(double), hipMemcpyDeviceToDevice, st));   // version 0
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, A);
     HIPCHK(h, hipGetLastError());
