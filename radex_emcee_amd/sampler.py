@@ -410,7 +410,9 @@ class DeviceEnsembleSampler:
     nens      independent ensembles advancing together (BASELINE config 3: one per source);
               ens_src[nens] = source slot of each (default: slot 0 for all)
     schedule  "dataflow" (default): the chain as one persistent kernel (per GPU) whose tasks start when
-              their two input walkers are final; "halfsteps": one propose / solve / accept round per half-step
+              their two input walkers are final -- or earlier, on the newest final position of a walker that is
+              still being updated (Engine.set_sampler_speculation; the same chain either way);
+              "halfsteps": one propose / solve / accept round per half-step
     group     torch.distributed group, one process per GPU: the proposals of every half-step are dealt out
               in contiguous blocks, one per rank (the reference's Pool.map over walkers,
               emcee_radex.py:480-488).  schedule="dataflow": every rank runs its block's tasks in its own
