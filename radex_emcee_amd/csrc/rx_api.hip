@@ -224,7 +224,7 @@ struct rx_handle {
         char *base[RX_MAX_RANKS] = {};
         bool opened[RX_MAX_RANKS] = {};          // mapped with hipIpcOpenMemHandle (to be closed)
         char **d_bases = nullptr;                // device copy of base[]
-        unsigned long long off_version = 0, off_done = 0, off_abort = 0, off_lnp = 0, off_nacc = 0, off_hist = 0;
+        unsigned long long off_version = 0, off_done = 0, off_abort = 0, off_lnp = 0, off_nacc = 0, off_hist = 0, off_pend = 0, off_pendver = 0;
         bool connected = false, begun = false;
         int memkind = 0;                         // 1 fine-grained, 2 uncached, 3 plain hipMalloc
     } peer;
@@ -1168,9 +1168,11 @@ int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwal
     P.off_version = off; off = up(off + N * sizeof(uint32_t));
     P.off_done = off;    off = up(off + PEER_RING * sizeof(uint32_t));
     P.off_abort = off;   off = up(off + sizeof(uint32_t));
+    P.off_pendver = off; off = up(off + (size_t)rxs::PEND_SLOTS * N * sizeof(uint32_t));     // (zeroed with the counters by rx_sampler_peer_begin)
     P.off_nacc = off;    off = up(off + N * sizeof(int32_t));
     P.off_lnp = off;     off = up(off + N * sizeof(double));
     P.off_hist = off;    off = up(off + (size_t)PEER_RING * N * ndim * sizeof(double));
+    P.off_pend = off;    off = up(off + (size_t)rxs::PEND_SLOTS * N * ndim * sizeof(double));
     P.bytes = off;
     // fine-grained device memory: writes of a peer GPU become visible to this GPU's system-scope loads while
     // both kernels run (coarse-grained allocations are only coherent at kernel boundaries)
@@ -1279,11 +1281,12 @@ int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, in
     A.timeout_ticks = h->sampler_timeout_ticks;
     A.stats = h->stats_on ? h->d_stats : nullptr;
     A.speculate = (occ == 1) && h->speculation != 0;
+    if (A.speculate) { A.pend = (double *)(P.own + P.off_pend); A.pend_version = (uint32_t *)(P.own + P.off_pendver); }
     // (nranks = 1 runs the very same kernel in its one-GPU form on the replica block)
     A.nranks = P.nranks; A.rank = P.rank; A.t_lo = (uint32_t)lo; A.t_n = (uint32_t)(hi - lo);
     A.peers = P.d_bases;
     A.off_version = P.off_version; A.off_done = P.off_done; A.off_abort = P.off_abort;
-    A.off_lnp = P.off_lnp; A.off_nacc = P.off_nacc; A.off_hist = P.off_hist;
+    A.off_lnp = P.off_lnp; A.off_nacc = P.off_nacc; A.off_hist = P.off_hist; A.off_pend = P.off_pend; A.off_pendver = P.off_pendver;
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, A);
     HIPCHK(h, hipGetLastError());
