@@ -239,18 +239,22 @@ int rx_set_sampler_grid_limit(rx_handle *h, int cus);
  * copies the counters accumulated since the last call into out6 (may be NULL), zeroes them and switches the
  * counting on (enable = 1) or off for the launches that follow.  out6: [0] tasks, [1] tasks whose proposal
  * reached the solver (lnprior finite), [2] RADEX iterations summed over them, [3] solves that stopped at
- * maxiter, [4] 100 MHz wall-clock ticks summed over the tasks between "inputs final" and "result published",
- * [5] ticks summed over the tasks between "dequeued" and "inputs final" (polling).                     */
+ * maxiter, [4] 100 MHz wall-clock ticks summed over the tasks: the evaluation that stands (inputs read ->
+ * log-probability known), [5] ticks summed over the tasks between "dequeued" and the first evaluation (polling).
+ * [1]-[3] describe the evaluation that stands, i.e. the chain's proposals, whatever head starts were taken. */
 int rx_sampler_stats(rx_handle *h, int enable, uint64_t *out6);
-/* The dataflow sampler's head start (both forms, one GPU and peers).  A task whose partner's LAST update is still
- * pending starts on the partner's previous position instead of sleeping; a stretch move is rejected more often
- * than not, and a rejected update leaves the position as it was.  When the partner's version arrives the two
- * positions are compared bit for bit: equal, the result stands; different, the task is evaluated again from the
- * right position.  The chain is the same chain, bit for bit; only idle time is spent.
+/* The dataflow sampler's head starts (both forms, one GPU and peers).  A task that reads a walker which is still
+ * being updated -- its own or its partner -- does not sleep: it evaluates its proposal from that walker's newest
+ * final position (a stretch move is rejected more often than not, and a rejected update leaves the walker where
+ * it was) or from the proposal the pending task has published, and keeps each evaluation with the positions it
+ * assumed.  When both walkers are final their real positions are compared bit for bit with those assumptions: a
+ * match is the evaluation of the chain's proposal; none: the task is evaluated from the real positions, as
+ * without a head start.  The chain is the same chain, bit for bit; only idle time is spent.
  *   mode  -1 (default) and 1: on; 0: off.  The head start exists for launches that run one wavefront per SIMD
  *         (the latency regime: up to 1536 tasks per half-step on 256 CUs, idle wavefronts); where two wavefronts
  *         share a SIMD a wasted evaluation slows its neighbour down, and the mode is ignored (measured 2-4 % slower).
- * rx_sampler_spec_stats: out2[0] tasks that took the head start, out2[1] of those, tasks evaluated twice --
+ * rx_sampler_spec_stats: out2[0] tasks that took a head start, out2[1] of those, tasks evaluated again from the
+ * real positions (every hypothesis wrong) --
  * as counted up to the most recent rx_sampler_stats call that read the counters.                              */
 int rx_set_sampler_speculation(rx_handle *h, int mode);
 int rx_sampler_spec_stats(rx_handle *h, uint64_t *out2);
