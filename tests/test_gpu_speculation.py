@@ -95,3 +95,20 @@ def test_two_components_and_two_waves_per_simd(eng, mol):
             assert np.array_equal(a, b)
     assert s_auto["head_starts"] == 0 and s_on["head_starts"] == 0
     _truth_source(eng, mol, workloads.config2(8))
+
+
+def test_argument_errors_of_the_new_entry_points(eng):
+    """rx_set_sampler_speculation / rx_sampler_spec_stats / rx_lnprior_batch: bad arguments are errors, not crashes."""
+    import ctypes as C
+    from radex_emcee_amd.engine import EngineError
+    L, h = eng._L, eng._h
+    assert L.rx_set_sampler_speculation(h, 2) != 0 and L.rx_set_sampler_speculation(h, -2) != 0
+    assert L.rx_set_sampler_speculation(h, -1) == 0
+    assert L.rx_sampler_spec_stats(h, None) != 0
+    out = (C.c_double * 1)()
+    p = (C.c_double * 4)(4.0, 1.8, 17.0, -9.0)
+    assert L.rx_lnprior_batch(h, 0, 0, p, out) == 0                       # no walkers: nothing to do
+    assert L.rx_lnprior_batch(h, 61, 1, p, out) != 0                      # a slot that was never set
+    assert L.rx_lnprior_batch(h, 0, 1, None, out) != 0
+    with pytest.raises(EngineError):
+        eng.lnprior_batch(np.zeros((1, 4)), src=61)
