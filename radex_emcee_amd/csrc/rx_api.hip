@@ -489,7 +489,8 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     kernel_fn k = kernel_for(h->NL, occ, is_exact(h));
-    HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
+    // (every wavefront of the grid takes the item of its own index first, without the queue: the counter starts behind them)
+    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->d_queue, (int)(blocks * RXK_WAVES_PER_BLOCK), 1, st));
     if (e0) HIPCHK(h, hipEventRecord(e0, st));
     // more items than resident wavefronts: hand the walkers out hottest first (see rx_order_bucket)
     a.order = nullptr;
