@@ -3,8 +3,11 @@
 
     python tests/golden/make_ref_vectors.py
 
+    python tests/golden/make_ref_vectors.py --reuse-only     (only ref_matrix_reuse.json)
+
 Writes tests/golden/ref_escprob.json, ref_backrad.json, ref_lubksb.json,
-ref_matrix.json.  Every number in them was computed by the reference's own
+ref_matrix.json and ref_matrix_reuse.json (the `reuse_last=True` entry of the drivers, see
+reuse_vectors()).  Every number in them was computed by the reference's own
 machine code (/root/reference/emcee/pyradex/radex/radex.so, routines
 escprob_, backrad_, lubksb_, matrix_) loaded through oracle/macho_ref.py; the
 iteration driver around matrix_ follows emcee/pyradex/core.py:896-925.
@@ -94,7 +97,144 @@ def run_reference_loop(R, v, mol, reuse_last=False, miniter=10, maxiter=200):
     return it, conv, snaps
 
 
+def surf_brightness(mol, tex, taul, backi):
+    """core.py:986-1003 minus the background (base_class.py:275-277), astropy constants."""
+    thc, fk = 3.9728917142978573e-16, 1.4387768775039338
+    x = np.asarray(mol.xnu)
+    with np.errstate(all="ignore"):
+        ftau = np.exp(-taul)
+        bnutex = thc * x ** 3 / (np.exp(fk * x / tex) - 1.0)
+        return backi * ftau + bnutex * (1.0 - ftau) - backi
+
+
+def reuse_vectors():
+    """The start mode the drivers actually use: run_radex(reuse_last=True)
+    [/root/reference/emcee/emcee_radex.py:127, emcee_radex_2comp.py:133,141,158] -> _iter_counter = 1
+    [emcee/pyradex/core.py:896]: matrix_ is entered at niter = 1 on whatever xpop / tex / taul the worker's
+    COMMON blocks hold -- zeros on a fresh pool worker, the previous walker's converged state afterwards.
+
+    ref_matrix_reuse.json holds, all computed by the reference binary's own readdata_ / backrad_ / matrix_:
+      * chains: walkers evaluated BACK TO BACK on one mapped image, like one pool worker does -- the first one
+        from the zeroed COMMON blocks of a fresh image -- for a 1e-3 ball (emcee_radex.py:477), a 0.15-dex
+        ball (a stationary-like ensemble) and prior-box neighbours, plus a toy-molecule chain; per walker:
+        iteration count, conv flag, final xpop / tex / taul and snapshots of the first warm iterations;
+      * stats: the same three ensembles with 200 walkers each, warm (as above) against cold (niter = 0
+        first, on a second image): iteration counts and the relative deviation of the line surface
+        brightness of J = 1..10 -- the reference's own history dependence on record.
+    """
+    mol = O.Molecule(SYNTH_CO_PATH)
+    toy = O.Molecule(TOY_PATH)
+    tbg = 2.7315 * 3.5
+    truth = np.array([3.5, 2.0, 17.5])                      # BASELINE config 2's truth (n, T, N)
+    lo = np.array([2.0, np.log10(tbg), 15.5])
+    hi = np.array([7.0, 3.0, 19.5])
+
+    def ensemble(kind, n, rng):
+        if kind == "ball_1e-3":
+            return truth + 1e-3 * rng.standard_normal((n, 3))
+        if kind == "ball_0.15dex":
+            return truth + 0.15 * rng.standard_normal((n, 3))
+        out = []
+        while len(out) < n:                                # prior box of emcee_radex.py:439-442 and 10 < N - n < 17.5
+            p = lo + (hi - lo) * rng.random(3)
+            if 10.0 < p[2] - p[0] < 17.5:
+                out.append(p)
+        return np.array(out)
+
+    def evaluate(R, v, m, molfile, dens, tkin, cdmol, tbg_, reuse, method=2, snaps_at=(1, 2, 5)):
+        R.readdata(molfile, tkin, dens)
+        v["method"][0] = method
+        v["cdmol"][0] = cdmol
+        v["deltav"][0] = 1e5
+        v["tbg"][0] = tbg_
+        R.backrad()
+        n, L = m.nlev, m.nline
+        it = 1 if reuse else 0
+        conv = 0
+        last = v["xpop"][:n].copy()
+        snaps = {}
+        while not conv:
+            if it >= 200:
+                break
+            conv = R.matrix(it, conv)
+            x = v["xpop"][:n]
+            if it in snaps_at:
+                snaps[str(it)] = dict(xpop=fl(x), tex=fl(v["tex"][:L]), taul=fl(v["taul"][:L]))
+            if np.abs(last - x).sum() < 1e-16 and it > 10:
+                break
+            last = x.copy()
+            it += 1
+        return it, int(conv), snaps
+
+    def record(v, m, it, conv, snaps, **kw):
+        return dict(kw, niter=int(it), conv=int(conv), snapshots=snaps, xpop=fl(v["xpop"][:m.nlev]),
+                    tex=fl(v["tex"][:m.nline]), taul=fl(v["taul"][:m.nline]))
+
+    chains = []
+    rng = np.random.default_rng(20251004)
+    for kind in ("ball_1e-3", "ball_0.15dex", "prior_box"):
+        R = RefRadex()                                     # a fresh image = a fresh pool worker: COMMON blocks zeroed
+        v = R.views()
+        assert not np.any(v["xpop"][:mol.nlev]) and not np.any(v["tex"][:mol.nline]) and not np.any(v["taul"][:mol.nline])
+        walkers = []
+        for p in ensemble(kind, 6, rng):
+            dens = {2: 0.25 * 10 ** p[0], 3: 0.75 * 10 ** p[0]}
+            it, conv, snaps = evaluate(R, v, mol, SYNTH_CO_PATH, dens, 10 ** p[1], 10 ** p[2], tbg, True)
+            walkers.append(record(v, mol, it, conv, snaps, density={str(k): float(x) for k, x in dens.items()},
+                                  tkin=float(10 ** p[1]), cdmol=float(10 ** p[2])))
+            print("reuse", kind, "niter", it, "conv", conv)
+        assert not R.trap_log, R.trap_log
+        chains.append(dict(kind=kind, mol="co_synth", method=2, tbg=tbg, deltav_kms=1.0, walkers=walkers))
+    # a non-ladder toy molecule, sphere geometry, one partner
+    R = RefRadex()
+    v = R.views()
+    walkers = []
+    for dens1, tkin, cdmol in ((1e4, 25.0, 1e14), (3e5, 70.0, 1e17), (1e3, 10.0, 1e16), (2e4, 40.0, 3e15)):
+        it, conv, snaps = evaluate(R, v, toy, TOY_PATH, {1: dens1}, tkin, cdmol, 2.73, True, method=1)
+        walkers.append(record(v, toy, it, conv, snaps, density={"1": dens1}, tkin=tkin, cdmol=cdmol))
+    assert not R.trap_log, R.trap_log
+    chains.append(dict(kind="toy6_sphere", mol="toy6", method=1, tbg=2.73, deltav_kms=1.0, walkers=walkers))
+
+    # ---- the reference's own history dependence: warm (reuse_last=True, back to back) against cold ----------
+    stats = []
+    for kind in ("ball_1e-3", "ball_0.15dex", "prior_box"):
+        Rw, Rc = RefRadex(), RefRadex()
+        vw, vc = Rw.views(), Rc.views()
+        rng = np.random.default_rng(77)
+        nw, nc, dev, both = [], [], [], 0
+        for p in ensemble(kind, 200, rng):
+            dens = {2: 0.25 * 10 ** p[0], 3: 0.75 * 10 ** p[0]}
+            itw, cw, _ = evaluate(Rw, vw, mol, SYNTH_CO_PATH, dens, 10 ** p[1], 10 ** p[2], tbg, True, snaps_at=())
+            itc, cc, _ = evaluate(Rc, vc, mol, SYNTH_CO_PATH, dens, 10 ** p[1], 10 ** p[2], tbg, False, snaps_at=())
+            nw.append(itw); nc.append(itc)
+            if cw and cc:                                  # both converged: how far apart are the answers?
+                both += 1
+                sw = surf_brightness(mol, vw["tex"][:40].copy(), vw["taul"][:40].copy(), vw["backi"][:40].copy())[:10]
+                sc = surf_brightness(mol, vc["tex"][:40].copy(), vc["taul"][:40].copy(), vc["backi"][:40].copy())[:10]
+                with np.errstate(all="ignore"):
+                    d = np.abs(sw - sc) / np.abs(sc)
+                d = d[np.isfinite(d)]                      # (a maser walker: NaN brightness both ways)
+                if len(d):
+                    dev.append(float(d.max()))
+        assert not Rw.trap_log and not Rc.trap_log
+        dev = np.array(dev)
+        stats.append(dict(kind=kind, walkers=200, both_converged=both, compared=int(len(dev)),
+                          niter_cold_mean=float(np.mean(nc)), niter_warm_mean=float(np.mean(nw)),
+                          maxiter_cold=int(np.sum(np.array(nc) >= 200)), maxiter_warm=int(np.sum(np.array(nw) >= 200)),
+                          flux_rel_dev_median=float(np.median(dev)), flux_rel_dev_p90=float(np.percentile(dev, 90)),
+                          flux_rel_dev_max=float(dev.max()), frac_beyond_1e4=float(np.mean(dev > 1e-4))))
+        print("stats", stats[-1])
+    json.dump(dict(source="radex.so:_readdata_/_backrad_/_matrix_ driven by core.py:896-925 with reuse_last=True "
+                          "(_iter_counter = 1), walkers back to back on one image; the first of a chain on a fresh image",
+                   chains=chains, stats=stats,
+                   stats_note="warm = reuse_last=True back to back on one image; cold = niter 0 first (the engine's mode); "
+                              "flux deviation = max over J=1..10 of |S_warm - S_cold| / |S_cold| for walkers converged both ways"),
+              open(os.path.join(HERE, "ref_matrix_reuse.json"), "w"), indent=0)
+
+
 def main():
+    if "--reuse-only" in sys.argv:
+        return reuse_vectors()
     assert os.path.exists(TOY_PATH), "toy6.dat missing"
     R = RefRadex()
     v = R.views()
@@ -212,6 +352,7 @@ def main():
                    note="molecule tables, crate and ctot by the binary's own readdata_ on the committed .dat files",
                    cases=out_m), open(os.path.join(HERE, "ref_matrix.json"), "w"), indent=0)
     print("traps:", R.trap_log)
+    reuse_vectors()
 
 
 if __name__ == "__main__":
