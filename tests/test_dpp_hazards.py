@@ -4,7 +4,9 @@
    must not have written in the two preceding wait states; hipcc pads nothing inside or around asm
    statements.  A violation made rx_lubksb_kernel<32> return wrong solutions on the GPU.
 2. The persistent item / task loops of rx_solve_kernel and rx_sampler_kernel must be scalar loops: in
-   the exec-masked form hipcc 7.2 sometimes builds, wavefronts have been seen to loop for ever."""
+   the exec-masked form hipcc 7.2 sometimes builds, wavefronts have been seen to loop for ever.
+3. No register-allocator copy / spill traffic in front of the EXEC restore of a control-flow join (the cause of
+   round 3's two-wavefront memory fault: profiles/r4_fault_bisect.txt, scripts/check_spill_exec.py)."""
 import os
 import subprocess
 import sys
@@ -39,3 +41,30 @@ def test_item_loops_are_scalar_loops(asm_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert "0 with an exec-masked item loop" in last and not last.startswith("0 persistent"), last
+
+
+def test_spill_checker_flags_the_faulting_build():
+    """The checker on the excerpt of the build that faulted on the GPU (round 3; bisected in round 4): it must find the
+    live-range-split copy in front of the EXEC restore -- and nothing once the two instructions are swapped, which is the
+    change that made that build run."""
+    chk = os.path.join(ROOT, "scripts", "check_spill_exec.py")
+    bad = os.path.join(ROOT, "tests", "golden", "join_copy_excerpt.s")
+    r = subprocess.run([sys.executable, chk, bad], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "v_mov_b32_e32 v78, v74" in r.stdout and "1 finding(s)" in r.stdout, r.stdout
+    lines = open(bad).read().split("\n")
+    i = next(k for k, l in enumerate(lines) if l.strip() == "v_mov_b32_e32 v78, v74")
+    lines[i], lines[i + 1] = lines[i + 1], lines[i]
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write("\n".join(lines))
+    r = subprocess.run([sys.executable, chk, f.name], capture_output=True, text=True, timeout=120)
+    os.unlink(f.name)
+    assert r.returncode == 0 and "0 finding(s)" in r.stdout, r.stdout
+
+
+def test_no_vector_op_in_front_of_an_exec_restore(asm_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_spill_exec.py"), asm_path],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "0 finding(s)" in last and not last.startswith("0 functions"), last
