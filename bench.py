@@ -13,19 +13,23 @@ LOCAL_RANK / WORLD_SIZE / MASTER_* set for them; the parent never touches a GPU 
 return code); under torch.distributed.run the ranks already exist.  Rank 0 prints the line; "n_gpus" is the
 world size as an all_reduce of ones over the process group found it.
 
-N = 1: the batch is the 1024 walkers of config 2.
-N > 1: the partitioning north_star names -- the global batch (N x 1024 walkers; rank r's contiguous
-block is the config-2 draw with seed 1234 + r) is sharded in blocks of 1024, every rank evaluates its
-block on its GPU and ONE all_gather_into_tensor of the log-probabilities (RCCL over xGMI, device
-buffers) makes the full vector available on every rank before the stretch move would run: the
-collective is INSIDE the timed region.  Per-GPU work is fixed -> "scaling": "weak"; at N = 1 the
-collective degenerates and the line is the single-GPU number.  The strong-scaling shapes of
-BASELINE configs[3] and [4] (2048 two-component walkers; 65536 walkers: ONE ensemble each, whatever N)
+N = 1: the batch is the 1024 walkers of config 2 (numpy default_rng(1234)).
+N > 1: BASELINE.json's metric is "1024 walkers ... at 1/2/4/8 MI355X": the headline is STRONG scaled -- the SAME 1024
+walkers (seed 1234 on every rank), sharded in contiguous blocks of 1024 / N, every rank evaluates its block on its
+GPU and ONE all_gather_into_tensor of the log-probabilities (RCCL over xGMI, device buffers) makes the full vector
+available on every rank before the stretch move would run: the collective is INSIDE the timed region; "value" =
+1024 x steps / time, "scaling": "strong".  (A launch lasts as long as its slowest walker, so this number cannot grow
+with N: expect it flat.)  The weak-scaled pass of earlier rounds -- N x 1024 walkers, rank r's block the config-2 draw
+with seed 1234 + r -- is reported under "weak".  "preflight" records what the run found: devices, the
+hipDeviceCanAccessPeer matrix with link type and hops, the world size as the process group counts it, and per shape
+the schedule that actually ran and why.  The strong-scaling shapes of BASELINE configs[1], [3] and [4] (the 1024
+prior-box walkers; 2048 two-component walkers; 65536 walkers: ONE ensemble each, whatever N)
 are timed through the device-resident sampler ("sharded": {...}, walker-steps/s): first on rank 0's GPU
 alone (the one-GPU dataflow kernel -- the number every multi-GPU schedule has to beat), then across the N
-ranks with the peer-write dataflow schedule (every rank's persistent kernel publishes into all replicas
-over xGMI, no collective) and with the half-step schedule north_star spells out (block evaluation per rank,
-ONE all_gather of log-probabilities per half-step), each with its speedup over the one-GPU number.  The 16
+ranks with the peer-write dataflow schedule (opt-in; every rank's persistent kernel publishes into all replicas
+over xGMI, no collective; the sampler first checks its first steps against the half-step schedule, bit for bit, on
+every rank) and with the half-step schedule north_star spells out (block evaluation per rank, ONE all_gather of
+log-probabilities per half-step), each with its speedup over the one-GPU number.  The 16
 independent ensembles of configs[2] are dealt out 16/N per rank as replicas (no collective).
 Rank 0 prints ONE JSON line.
 """
@@ -45,6 +49,18 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_EVAL = 40.0                 # 4 x f64 params in + 1 x f64 lnp out
 def flops_per_eval(niter_mean, n=41, L=40, ncoll=820, npart=2):
     return niter_mean * (2.0 / 3.0 * n ** 3 + 7.0 * n * n + 60.0 * L) + 10.0 * ncoll * npart
+def eval_fields(stt, walker_steps_per_s):
+    """one evaluation = one lnprob that REACHES THE SOLVER.  From the dataflow kernel's own counters
+    (rx_sampler_stats: tasks, tasks whose proposal passed the prior, RADEX iterations summed over their solves)."""
+    tasks, solved = max(1, stt["tasks"]), max(1, stt["solved"])
+    frac = stt["solved"] / tasks
+    ev = walker_steps_per_s * frac
+    fl = stt["niter_sum"] / solved * (2.0 / 3.0 * 41 ** 3 + 7.0 * 41 * 41 + 60.0 * 40) + 10.0 * 820 * 2 * (stt["niter_sum"] > 0)
+    return {"proposals_outside_the_prior": round(1.0 - frac, 4), "evals_reaching_solver_per_s": round(ev, 1),
+            "niter_per_eval": round(stt["niter_sum"] / solved, 2),
+            "useful_fp64_tflops": round(ev * fl / 1e12, 3), "useful_fp64_frac": round(ev * fl / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4)}
+
+
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6             # MI355X datasheet fp64 vector (SURVEY 8d)
 
@@ -104,14 +120,16 @@ def config0_device(device):
     sampler = L.EnsembleSampler(400, 4, L.lnprob, args=(c["Jup"], truth, 0.1 * truth), kwargs={"bounds": c["bounds"]}, seed=0)
     sampler.run_mcmc(c["walkers"], 2, store=False)                              # (first launch: module load)
     sampler.reset()
+    R.sampler_stats(True)
     t0 = time.perf_counter()
     sampler.run_mcmc(c["walkers"], 200)
     d = time.perf_counter() - t0
-    return {"workload": "BASELINE configs[0]: APM08279+5255 stand-in (z=3.911, Jup 1,2,4,6,9,10,11), 1 component, "
-                        "400 walkers x 200 steps through likelihood.EnsembleSampler (the reference's call site), chain on the device",
-            "wall_s": round(d, 4), "walker_steps_per_s": round(400 * 200 / d, 1),
-            "acceptance": round(float(sampler.acceptance_fraction.mean()), 3),
-            "schedule": sampler.last_schedule}
+    stt = R.sampler_stats(False)
+    return dict({"workload": "BASELINE configs[0]: APM08279+5255 stand-in (z=3.911, Jup 1,2,4,6,9,10,11), 1 component, "
+                             "400 walkers x 200 steps through likelihood.EnsembleSampler (the reference's call site), chain on the device",
+                 "wall_s": round(d, 4), "walker_steps_per_s": round(400 * 200 / d, 1),
+                 "acceptance": round(float(sampler.acceptance_fraction.mean()), 3),
+                 "schedule": sampler.last_schedule}, **eval_fields(stt, 400 * 200 / d))
 
 
 def config0_cpu(cores):
@@ -234,18 +252,23 @@ def main():
             print("bench.py: --gpus %d but the process group has %d ranks; reporting %d" % (args.gpus, world, world),
                   file=sys.stderr)
 
-    # this rank's block of the global batch: same distribution, rank-specific seed
-    cfg = workloads.config2(nw, seed=1234 + rank)
+    # The headline batch: the SAME 1024 config-2 walkers on every rank (seed 1234); rank r evaluates the contiguous block
+    # [r * per, (r + 1) * per) of them -- strong scaling, BASELINE.json's "1024 walkers ... at 1/2/4/8 MI355X"
+    from radex_emcee_amd.sampler import block_partition
+    cfg = workloads.config2(nw, seed=1234)
     eng = Engine(device=local)
     eng.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
     truth_flux = eng.model_flux_batch(cfg["truth"][None, :])[0]
     eng.set_source(cfg["tbg"], cfg["Jup"], truth_flux, 0.1 * truth_flux, cfg["bounds"])
+    lo, hi, per = block_partition(nw, world, rank)
+    nmine = hi - lo
 
-    P = torch.from_numpy(cfg["walkers"]).to(dev)
-    lnp = torch.empty(nw, dtype=torch.float64, device=dev)
-    st = torch.empty(nw, dtype=torch.int32, device=dev)
-    nit = torch.empty(nw, dtype=torch.int32, device=dev)
-    lnp_all = torch.empty(nw * world, dtype=torch.float64, device=dev)
+    P_all = torch.from_numpy(cfg["walkers"]).to(dev)
+    P = P_all[lo:hi].contiguous()
+    lnp = torch.full((per,), float("-inf"), dtype=torch.float64, device=dev)      # (a short last block stays padded with -inf)
+    st = torch.empty(max(nmine, 1), dtype=torch.int32, device=dev)
+    nit = torch.empty(max(nmine, 1), dtype=torch.int32, device=dev)
+    lnp_all = torch.empty(per * world, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def gather(out, mine):
@@ -257,66 +280,117 @@ def main():
             dist.all_gather_into_tensor(out, mine)
 
     def step():
-        eng.lnprob_batch_torch(P, lnp, st, nit, stream=stream)
+        if nmine:
+            eng.lnprob_batch_torch(P, lnp[:nmine], st, nit, stream=stream)
         if use_dist:
-            gather(lnp_all, lnp)                   # log-probabilities of the whole batch on every rank
+            gather(lnp_all, lnp)                   # log-probabilities of all 1024 walkers on every rank
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, nsteps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            fn()
+        barrier()
+        d = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([d], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            d = float(tmax.item())
+        return d
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(step, args.steps)
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         # the gathered vector is the same on every rank and holds this rank's block where it belongs
-        assert torch.equal(torch.nan_to_num(lnp_all[rank * nw:(rank + 1) * nw], neginf=-1e300),
-                           torch.nan_to_num(lnp, neginf=-1e300))
+        assert torch.equal(torch.nan_to_num(lnp_all[rank * per:rank * per + nmine], neginf=-1e300),
+                           torch.nan_to_num(lnp[:nmine], neginf=-1e300))
 
-    # kernel time from HIP events recorded on the launch stream (inside the library)
+    # kernel time from HIP events recorded on the launch stream (inside the library): this rank's block
     kreps = max(5, min(50, args.steps))
-    kms = eng.time_lnprob_torch(P, lnp, st, nit, reps=kreps, stream=stream)
-    nitc = nit.cpu().numpy()
-    stc = st.cpu().numpy()
+    kms = eng.time_lnprob_torch(P, lnp[:nmine], st, nit, reps=kreps, stream=stream) if nmine else 0.0
+    nitc = nit[:nmine].cpu().numpy()
+    stc = st[:nmine].cpu().numpy()
+    if use_dist and world > 1:                     # the statistics of the whole batch, not of rank 0's block
+        allst = [None] * world
+        dist.all_gather_object(allst, (stc, nitc))
+        stc = np.concatenate([a for a, _ in allst])
+        nitc = np.concatenate([b for _, b in allst])
     solved = int((stc != 3).sum())
     n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
 
+    # ---- the weak-scaled pass of rounds 1-3 (N > 1 only): N x 1024 walkers, a different draw per rank -------------
+    weak = None
+    if use_dist and world > 1:
+        cfgw = workloads.config2(nw, seed=1234 + rank)
+        Pw = torch.from_numpy(cfgw["walkers"]).to(dev)
+        wl = torch.empty(nw, dtype=torch.float64, device=dev)
+        ws_, wn_ = torch.empty(nw, dtype=torch.int32, device=dev), torch.empty(nw, dtype=torch.int32, device=dev)
+        wall = torch.empty(nw * world, dtype=torch.float64, device=dev)
+
+        def wstep():
+            eng.lnprob_batch_torch(Pw, wl, ws_, wn_, stream=stream)
+            gather(wall, wl)
+        wstep()
+        dw = timed(wstep, args.steps)
+        weak = {"scaling": "weak", "walkers_total": nw * world, "walkers_per_gpu": nw, "value": round(nw * world * args.steps / dw, 1),
+                "unit": "evals/s", "ms_per_step": round(dw / args.steps * 1e3, 4),
+                "note": "global batch of %d walkers (rank r: the config-2 draw with seed 1234 + r) in blocks of %d, all_gather of the "
+                        "log-probabilities inside the timed step; NOT BASELINE's metric (which keeps 1024 walkers)" % (nw * world, nw)}
+
+    # ---- preflight: what this run found (filled in further by the sharded section) ---------------------------------
+    from radex_emcee_amd.engine import peer_topology
+    ndev = torch.cuda.device_count()
+    LINK = {0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi", -1: "unknown"}
+    pre = {"world_size_env": world, "world_size_counted_by_all_reduce": n_confirmed,
+           "backend": (dist.get_backend() if use_dist else None), "ranks_share_one_gpu": bool(share),
+           "devices_visible": ndev, "device_of_rank0": torch.cuda.get_device_name(dev),
+           "peer_access": None, "schedules": {}}
+    if rank == 0:
+        mat = []
+        for a in range(ndev):
+            row = []
+            for b in range(ndev):
+                t = peer_topology(a, b)
+                row.append(None if t is None else {"can_access_peer": t[0], "link": LINK.get(t[1], str(t[1])), "hops": t[2]})
+            mat.append(row)
+        pre["peer_access"] = mat
+
     out = None
     if rank == 0:
-        evals = nw * world * args.steps
+        evals = nw * args.steps
         value = evals / dt
         niter_mean = float(nitc[stc != 3].mean()) if solved else 0.0
-        algo_bytes = ALGO_BYTES_PER_EVAL * nw
-        fl = flops_per_eval(niter_mean) * solved
+        algo_bytes = ALGO_BYTES_PER_EVAL * max(nmine, 1)
+        fl = flops_per_eval(float(nit[:nmine].cpu().numpy()[st[:nmine].cpu().numpy() != 3].mean()) if nmine else 0.0) * int(
+            (st[:nmine].cpu().numpy() != 3).sum())                       # of the launch the kernel time belongs to (rank 0's block)
         out = {
-            "metric": "walker-lnlike evals/sec (1024 walkers, CO 1-comp)",
+            "metric": "walker-lnlike evals/sec (1024 walkers, CO 1-comp)" if world == 1 else
+                      "walker-lnlike evals/sec (1024 walkers, CO 1-comp) at 1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "evals/s", "n_gpus": n_confirmed, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic CO SLED J=1..10, 1-component, "
-                                   "%d walkers uniform in the prior box per GPU, z=2.5" % nw
-                                   + ("" if world == 1 else "; global batch of %d walkers sharded in blocks of %d, "
-                                      "all_gather of log-probabilities (device, RCCL) inside the timed step" % (nw * world, nw)),
-                       "molecule": os.path.basename(eng.molfile), "walkers_per_gpu": nw,
+                                   "%d walkers uniform in the prior box (seed 1234), z=2.5" % nw
+                                   + ("" if world == 1 else "; the SAME %d walkers on %d GPUs in contiguous blocks of %d, ONE "
+                                      "all_gather of the log-probabilities (device, RCCL) inside the timed step" % (nw, world, per)),
+                       "molecule": os.path.basename(eng.molfile), "walkers": nw, "walkers_per_gpu": per,
                        "kernel": eng.kernel_name, "niter_mean": round(niter_mean, 2),
                        "niter_max": int(nitc.max()), "maxiter_walkers": int((stc == 1).sum()),
                        "collective": None if world == 1 else "all_gather_into_tensor(%d x f64) per step, %s"
-                                     % (nw * world, "gloo rehearsal on one GPU" if share else "nccl (RCCL)")},
+                                     % (per * world, "gloo rehearsal on one GPU" if share else "nccl (RCCL)")},
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (kms * 1e-3) / 1e9, 6),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": algo_bytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": round(kms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "path is fp64-VALU/latency bound (SURVEY 8d): the binding resource is in fp64_valu",
+                         "note": "path is fp64-VALU/latency bound (SURVEY 8d): the binding resource is in fp64_valu"
+                                 + ("" if world == 1 else "; launch = rank 0's block of %d walkers" % nmine),
                          "fp64_valu": {"bound": "fp64-valu", "achieved": round(fl / (kms * 1e-3) / 1e12, 4),
                                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": fl / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
@@ -326,9 +400,15 @@ def main():
                      "flops_per_eval": round(flops_per_eval(niter_mean), 1)},
             # share of the SIMD-time of the launch that executes iterations: the launch lasts as long as
             # its slowest walker (niter_max iterations on one SIMD) while the mean walker needs niter_mean
-            "simd_time_utilization": round(float(nitc.sum()) / (n_simd * max(1, int(nitc.max()))), 4),
+            "simd_time_utilization": round(float(nitc.sum()) / (n_simd * world * max(1, int(nitc.max()))), 4),
         }
-        out["roofline"]["traffic"] = _measured_traffic()
+        if world == 1:
+            out["roofline"]["traffic"] = _measured_traffic()
+        else:
+            out["weak"] = weak
+            out["speedup_note"] = ("a 1024-walker launch lasts as long as its slowest walker (200 iterations) on whichever GPU holds it: "
+                                   "the strong-scaled one-launch number is expected FLAT in N; what scales is under `sharded` and `weak`")
+        out["preflight"] = pre
 
     # ---- strong-scaling shapes through the device-resident sampler (all ranks take part) ------------
     if not args.no_sharded:
@@ -350,9 +430,14 @@ def main():
             barrier()
             return time.perf_counter() - ts
 
-        for name, ndim, nwk, nst in (("config4", 8, 2048, 12), ("config5", 4, 65536, 6)):
+        for name, ndim, nwk, nst in (("config2", 4, 1024, 60), ("config4", 8, 2048, 12), ("config5", 4, 65536, 6)):
+            if name == "config2" and world == 1:
+                continue                                 # (N = 1: this shape is `sampler_config2_prior_box` below, with the kernel's counters)
             try:
-                if name == "config4":
+                if name == "config2":                    # BASELINE configs[1] in the sampler: the headline's 1024 prior-box walkers as ONE ensemble
+                    c = cfg
+                    ens_src = None
+                elif name == "config4":
                     c = workloads.config4(nwk)
                     eng.set_source(c["tbg"], c["Jup"], np.ones(10), np.ones(10), c["bounds"], 2, c["T_d"], src=1)
                     tf = eng.model_flux_batch(c["truth"][None, :], src=1)[0]
@@ -364,11 +449,14 @@ def main():
                 rec = {"walkers": nwk, "ndim": ndim, "steps": nst, "scaling": "strong", "n_gpus": n_confirmed,
                        "proposals_per_half_step": nwk // 2, "proposals_per_rank": -(-(nwk // 2) // world)}
 
-                def entry(d, schedule, collective, base=None):
+                def entry(d, schedule, collective, base=None, stt=None):
                     e = {"schedule": schedule, "collective": collective, "ms_per_step": round(d / nst * 1e3, 3),
                          "walker_steps_per_s": round(nwk * nst / d, 1), "solves_per_s": round(nwk * nst * (ndim // 4) / d, 1)}
+                    if stt is not None and stt["tasks"]:     # (the kernel's counters: of THIS rank's tasks)
+                        e.update(eval_fields(stt, nwk * nst / d))
                     if base is not None:
                         e["speedup_vs_1gpu_dataflow"] = round(base / d, 3)
+                        e["speedup_vs_1gpu"] = e["speedup_vs_1gpu_dataflow"]
                     return e
 
                 # (1) ONE GPU, the dataflow kernel: the number every multi-GPU schedule has to beat (rank 0 alone)
@@ -377,19 +465,27 @@ def main():
                     smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src)
                     state = smp.run_mcmc(c["walkers"], 1, store=False)
                     torch.cuda.synchronize()
+                    eng.sampler_stats(True)
                     ts = time.perf_counter()
                     smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
                     torch.cuda.synchronize()
                     d1 = time.perf_counter() - ts
+                    st1 = eng.sampler_stats(False)
                     del smp
                 d1 = max_over_ranks(d1)
-                rec["one_gpu_dataflow"] = entry(d1, "dataflow: one persistent kernel on ONE GPU (rank 0 alone)", "none")
+                rec["one_gpu_dataflow"] = entry(d1, "dataflow: one persistent kernel on ONE GPU (rank 0 alone)", "none",
+                                                stt=st1 if rank == 0 else None)
                 if use_dist:
                     grp = dist.group.WORLD
-                    # (2) the same ensemble across the ranks, dataflow with peer writes (falls back by itself)
-                    smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp)
+                    # (2) the same ensemble across the ranks, dataflow with peer writes: opt-in, and the sampler compares its first
+                    # steps with the half-step schedule on every rank before it relies on the path (falls back by itself)
+                    smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp, schedule="dataflow")
                     d2 = max_over_ranks(timed_run(smp, c["walkers"], nst))
                     used = smp.last_schedule
+                    pre["schedules"][name] = {"requested": "dataflow-peer", "ran": used, "why": smp.schedule_reason,
+                                              "peer_verified_against_halfsteps": smp.peer_verified,
+                                              "verification": smp.peer_verify_detail,
+                                              "replicas_on_this_device": eng.sampler_peer_same_device() if smp.peer_state is True else None}
                     rec["multi_gpu_dataflow"] = entry(
                         d2, "dataflow-peer: one persistent kernel per rank, every result published into all replicas "
                             "(IPC-mapped fine-grained memory, system-scope stores over xGMI)" if used == "dataflow-peer"
@@ -399,6 +495,8 @@ def main():
                         "none on the data path; two host barriers per run_mcmc call" if used == "dataflow-peer"
                         else "all_gather_into_tensor per half-step", d1)
                     rec["multi_gpu_dataflow"]["ranks_share_one_gpu"] = bool(share)
+                    rec["multi_gpu_dataflow"]["schedule_actually_run"] = used
+                    rec["multi_gpu_dataflow"]["why"] = smp.schedule_reason
                     del smp
                     # (3) north_star's literal form: block evaluation per rank + ONE all_gather of log-probabilities per half-step
                     smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp, schedule="halfsteps")
@@ -515,12 +613,14 @@ def main():
                 sm3 = DeviceEnsembleSampler(1024, 4, engine=e3, nens=16, ens_src=np.arange(16), seed=11)
                 st3 = sm3.run_mcmc(c3b["walkers"], 2, store=False)
                 torch.cuda.synchronize()
+                e3.sampler_stats(True)
                 t3 = time.perf_counter()
                 sm3.run_mcmc(State(st3.coords, st3.log_prob), 10, store=False)
                 torch.cuda.synchronize()
                 d3 = time.perf_counter() - t3
                 out["config3"]["sampler"] = {"walker_steps_per_s": round(16 * 1024 * 10 / d3, 1), "steps": 10,
                                              "ms_per_step": round(d3 / 10 * 1e3, 3),
+                                             **eval_fields(e3.sampler_stats(False), 16 * 1024 * 10 / d3),
                                              "note": "16 chains advanced together on the device, walkers started in "
                                                      "the reference's ball (emcee_radex.py:477)"}
             e3.close()
@@ -530,7 +630,7 @@ def main():
             from radex_emcee_amd.sampler import DeviceEnsembleSampler, EnsembleSampler, State
             rs = np.random.RandomState(99)
             p0 = cfg["truth"] + 1e-3 * rs.randn(nw, 4)
-            def stats_fields(stt, nst_, ms_step):
+            def stats_fields(stt, nst_, ms_step, wsps=None):
                 tasks, solved = max(1, stt["tasks"]), max(1, stt["solved"])
                 task_us = stt["busy_ticks"] / tasks / 100.0               # 100 MHz wall clock
                 # a walker's own chain WITHOUT head starts: its task of this step after its task of the last one, after its
@@ -538,6 +638,7 @@ def main():
                 # longer waits for a rejected update of its own walker, and a step can be shorter than this.
                 floor_ms = 2.0 * task_us * 1e-3
                 return {"tasks": stt["tasks"], "proposals_outside_the_prior": round(1.0 - stt["solved"] / tasks, 4),
+                        **({} if wsps is None else {k: v for k, v in eval_fields(stt, wsps).items() if k != "proposals_outside_the_prior"}),
                         "niter_mean": round(stt["niter_sum"] / solved, 2),
                         "maxiter_fraction": round(stt["maxiter_solves"] / solved, 5),
                         "mean_task_us": round(task_us, 2), "mean_wait_for_inputs_us": round(stt["wait_ticks"] / tasks / 100.0, 2),
@@ -557,7 +658,7 @@ def main():
             sd = dsm.run_mcmc(State(sd.coords, sd.log_prob), nst, store=False)
             torch.cuda.synchronize()
             tsd = time.perf_counter() - ts
-            stats_ball = stats_fields(eng.sampler_stats(False), nst, tsd / nst * 1e3)
+            stats_ball = stats_fields(eng.sampler_stats(False), nst, tsd / nst * 1e3, nw * nst / tsd)
             # SURVEY 8(d) config 2 itself: the 1024 PRIOR-BOX walkers of the headline batch as the ensemble (half-step
             # batch N = 512), same schedule, 20 steps of burn-in, then 120 timed steps with the kernel's own counters
             dsp = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)
@@ -573,9 +674,13 @@ def main():
                 {"workload": "BASELINE configs[1] as SURVEY 8(d) states it for the sampler: the %d prior-box walkers of the "
                              "headline batch as ONE ensemble, half-step batch %d, dataflow schedule" % (nw, nw // 2),
                  "burn_in_steps": 20, "steps": nsp, "ms_per_step": round(tsp / nsp * 1e3, 4),
-                 "walker_steps_per_s": round(nw * nsp / tsp, 1), "unit": "walker-steps/s = lnlike evaluations/s",
+                 "walker_steps_per_s": round(nw * nsp / tsp, 1),
+                 "unit": "walker-steps/s; lnlike evaluations/s (SURVEY 8d: proposals that reach the solver) = evals_reaching_solver_per_s",
                  "acceptance": round(float(dsp.acceptance_fraction.mean()), 3)},
-                **stats_fields(eng.sampler_stats(False), nsp, tsp / nsp * 1e3))
+                **stats_fields(eng.sampler_stats(False), nsp, tsp / nsp * 1e3, nw * nsp / tsp))
+            # the line the >= 1e6 target of north_star is judged on, where it is met (the one-launch headline above is not it)
+            out["walker_steps_per_s_1024"] = out["sampler_config2_prior_box"]["walker_steps_per_s"]
+            out["evals_reaching_solver_per_s_1024"] = out["sampler_config2_prior_box"]["evals_reaching_solver_per_s"]
             # the same 140 steps with every task waiting for its partner (round 2's schedule): the same chain, slower
             eng.set_sampler_speculation(0)
             dsq = DeviceEnsembleSampler(nw, 4, engine=eng, seed=7)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 3
+#define RX_ABI_VERSION 4
 #define RX_MAX_SOURCES 64      /* sources resident in one handle (config 3: 16) */
 #define RX_MAX_NJ      32      /* observed lines per source                     */
 #define RX_MAX_LEVELS  64      /* one level per lane of a 64-wide wavefront     */
@@ -181,7 +181,7 @@ int rx_set_waves_per_simd(rx_handle *h, int waves);
  * the two walkers it reads are final (per-walker version counters in HBM) instead of waiting for the
  * whole previous half-step: a proposal that runs into maxiter delays only the tasks that depend on
  * its walker.  Asynchronous on `stream`; rx_sampler_wait synchronises the stream and reports
- * RX_E_TIMEOUT if a task gave up waiting (2 s wall clock -- the grid always drains).  The abort word is
+ * RX_E_TIMEOUT if a task gave up waiting (no finished task anywhere for 100 ms, rx_set_sampler_stall_ms -- the grid always drains).  The abort word is
  * sticky per handle: once raised it ends every later run of the handle at its first wait until
  * rx_sampler_wait has reported it (so a run enqueued before the wait cannot hide it); keep ONE async run
  * outstanding per handle when the result of each matters on its own.                          */
@@ -192,7 +192,7 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
                                 void *stream);
 int rx_sampler_wait(rx_handle *h, void *stream);   /* reports (and lowers) the sticky abort word */
 /* Longest time a task of the dataflow sampler polls for its inputs before it raises the abort flag
- * (default 2000 ms; real waits are milliseconds).  0 makes every wait that is not satisfied at once
+ * (default 10 s: a backstop behind the no-progress watchdog rx_set_sampler_stall_ms; real waits are milliseconds).  0 makes every wait that is not satisfied at once
  * give up: the safety path can be exercised on purpose (tests).                                  */
 int rx_set_sampler_timeout_ms(rx_handle *h, double ms);
 
@@ -235,6 +235,27 @@ int rx_sampler_peer_finish(rx_handle *h, double *d_coords, double *d_lnp, int32_
                            void *stream);
 int rx_sampler_peer_close(rx_handle *h);
 int rx_set_sampler_grid_limit(rx_handle *h, int cus);
+/* Residency and failure handling of the persistent kernels.
+ *   rx_sampler_peer_same_device  ranks of the connected group whose replica lives on THIS handle's device, own included (the
+ *                            library's per-device registry of the run, filled by rx_sampler_peer_connect).  Such ranks must
+ *                            all be resident at once -- a task may wait for a task of another rank -- so unless
+ *                            rx_set_sampler_grid_limit says otherwise rx_sampler_peer_run gives each an equal share of the
+ *                            device's compute units.  (Independent runs -- rx_sampler_run_async_device of two handles, two
+ *                            fits, two processes -- need nothing of the kind: a task only ever waits for tasks that were
+ *                            dequeued before it by wavefronts of ITS OWN launch, which are running.)
+ *   rx_set_sampler_stall_ms  no-progress watchdog of every wait inside the dataflow kernels (default 100 ms): a waiting task
+ *                            gives up -- abort word, all grids drain, RX_E_TIMEOUT from rx_sampler_wait / _peer_finish -- when
+ *                            no task of ANY rank has finished for that long while every rank's grid is running (a rank that is
+ *                            still loading its code object does not count as a stall).  A task lasts a few milliseconds at
+ *                            most.  rx_set_sampler_timeout_ms (default now 10 s) stays the flat bound of a single wait.
+ *   rx_sampler_peer_abort    raises the abort word in every connected replica from the HOST (a stream of its own): the rank
+ *                            whose launch failed ends the others' kernels at once instead of letting them run into the watchdog. */
+int rx_sampler_peer_same_device(const rx_handle *h);
+int rx_set_sampler_stall_ms(rx_handle *h, double ms);
+int rx_sampler_peer_abort(rx_handle *h);
+/* Preflight of a multi-GPU run (bench.py prints it): out3 = { hipDeviceCanAccessPeer(dev_a -> dev_b) (1 / 0, -1 = the query
+ * failed), link type and hop count of hipExtGetLinkTypeAndHopCount (-1 = unknown; type 4 = xGMI, 2 = PCIe) }.  No handle.   */
+int rx_peer_topology(int dev_a, int dev_b, int32_t *out3);
 /* Counters of the dataflow sampler's launches (benchmarks; off by default): waits for the handle's work,
  * copies the counters accumulated since the last call into out6 (may be NULL), zeroes them and switches the
  * counting on (enable = 1) or off for the launches that follow.  out6: [0] tasks, [1] tasks whose proposal

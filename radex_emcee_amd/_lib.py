@@ -29,8 +29,9 @@ EXPORTS = [
     "rx_sampler_peer_setup", "rx_sampler_peer_base", "rx_sampler_peer_connect", "rx_sampler_peer_begin",
     "rx_sampler_peer_run", "rx_sampler_peer_finish", "rx_sampler_peer_close", "rx_set_sampler_grid_limit",
     "rx_sampler_stats", "rx_lnprior_batch", "rx_set_sampler_speculation", "rx_sampler_spec_stats",
+    "rx_sampler_peer_same_device", "rx_set_sampler_stall_ms", "rx_sampler_peer_abort", "rx_peer_topology",
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
 RX_MAX_RANKS = 8
 RX_IPC_HANDLE_BYTES = 64
 
@@ -137,6 +138,10 @@ def load():
     L.rx_sampler_spec_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rx_set_sampler_speculation.argtypes = [vp, C.c_int]
     L.rx_time_lnprob_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, dp]
+    L.rx_sampler_peer_same_device.argtypes = [vp]
+    L.rx_set_sampler_stall_ms.argtypes = [vp, C.c_double]
+    L.rx_sampler_peer_abort.argtypes = [vp]
+    L.rx_peer_topology.argtypes = [C.c_int, C.c_int, ip]
     if L.rx_abi_version() != ABI_VERSION:
         raise EngineLibraryMissing("%s has ABI version %d, this package needs %d: rebuild it"
                                    % (LIB_PATH, L.rx_abi_version(), ABI_VERSION))

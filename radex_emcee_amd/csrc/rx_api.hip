@@ -210,7 +210,10 @@ struct rx_handle {
     DevBuf<uint32_t> w_pendver;      // [N]
     uint32_t *d_abort = nullptr;
     uint32_t *h_abort = nullptr;     // pinned mirror, filled by an async copy behind every async run
-    long long sampler_timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock: far beyond any real wait
+    long long sampler_timeout_ticks = 1000000000LL;  // 10 s of the 100 MHz wall clock: the longest single wait (a backstop; the watchdog below acts first)
+    long long sampler_stall_ticks = 10000000LL;      // 100 ms without ONE finished task anywhere while every rank's grid runs: give up
+                                                     //   (a task is a few ms at most: two solves of 200 iterations)
+    hipStream_t ctl_stream = nullptr;                // non-blocking: host writes into replicas while a persistent kernel runs (rx_sampler_peer_abort)
     int sampler_grid_limit = 0;      // > 0: the dataflow launches of the peer form occupy at most this many CUs (ranks sharing one GPU)
     unsigned long long *d_stats = nullptr;   // [8] counters of the dataflow launches since the last rx_sampler_stats
     int stats_on = 0;
@@ -224,8 +227,9 @@ struct rx_handle {
         char *base[RX_MAX_RANKS] = {};
         bool opened[RX_MAX_RANKS] = {};          // mapped with hipIpcOpenMemHandle (to be closed)
         char **d_bases = nullptr;                // device copy of base[]
-        unsigned long long off_version = 0, off_done = 0, off_abort = 0, off_lnp = 0, off_nacc = 0, off_hist = 0, off_pend = 0, off_pendver = 0;
+        unsigned long long off_version = 0, off_done = 0, off_abort = 0, off_alive = 0, off_lnp = 0, off_nacc = 0, off_hist = 0, off_pend = 0, off_pendver = 0;
         bool connected = false, begun = false;
+        int same_device = 1;                     // ranks whose replica lives on THIS device (own included): they share its CUs
         int memkind = 0;                         // 1 fine-grained, 2 uncached, 3 plain hipMalloc
     } peer;
     unsigned int *d_order_cnt = nullptr;
@@ -603,6 +607,7 @@ void rx_destroy(rx_handle *h)
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+    if (h->ctl_stream) (void)hipStreamDestroy(h->ctl_stream);
     h->s_params.release(); h->s_lnp.release(); h->s_flux.release(); h->s_cflux.release();
     h->s_in3.release(); h->s_dens.release(); h->s_xpop.release(); h->s_tex.release();
     h->s_tau.release(); h->s_sb.release(); h->s_src.release(); h->s_status.release();
@@ -1094,7 +1099,8 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     A.hist = h->w_hist.p; A.done = h->w_version.p + N; A.ring = RING;
     A.chain = d_chain; A.chain_lnp = d_chain_lnp;
     A.timeout_ticks = h->sampler_timeout_ticks;
-    A.stats = h->stats_on ? h->d_stats : nullptr;
+    A.stall_ticks = h->sampler_stall_ticks;
+    A.stats = (h->stats_on && blocks * RXK_WAVES_PER_BLOCK <= rxs::RXS_STAT_SLOTS) ? h->d_stats : nullptr;   // (one slot per wavefront)
     A.speculate = (occ == 1) && h->speculation != 0;        // (the head start exists in the one-wavefront-per-SIMD build only)
     if (A.speculate) { A.pend = h->w_pend.p; A.pend_version = h->w_pendver.p; }    // (proposals are published only for head starts)
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
@@ -1122,8 +1128,12 @@ static int peer_launch_shape(rx_handle *h, size_t tasks_per_half_step, size_t to
     const long need = (long)((total_tasks + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK);
     if (blocks > need) blocks = need;
     // (the limit is in compute units: the two-waves-per-SIMD build places blocks_per_cu2 workgroups on each)
-    const long lim = (long)h->sampler_grid_limit * (occ == 2 ? h->blocks_per_cu2 : 1);
-    if (h->sampler_grid_limit > 0 && blocks > lim) blocks = lim;
+    // ranks whose replicas live on ONE device share its compute units (every grid must be resident while the others run:
+    // a task may wait for a task of another rank): an explicit rx_set_sampler_grid_limit wins, otherwise an equal split
+    int cus = h->sampler_grid_limit;
+    if (cus <= 0 && h->peer.same_device > 1) cus = std::max(1, h->num_cu / h->peer.same_device);
+    const long lim = (long)cus * (occ == 2 ? h->blocks_per_cu2 : 1);
+    if (cus > 0 && blocks > lim) blocks = lim;
     if (blocks < 1) blocks = 1;
     *occ_out = occ; *blocks_out = blocks;
     return 0;
@@ -1169,6 +1179,7 @@ int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwal
     P.off_version = off; off = up(off + N * sizeof(uint32_t));
     P.off_done = off;    off = up(off + PEER_RING * sizeof(uint32_t));
     P.off_abort = off;   off = up(off + sizeof(uint32_t));
+    P.off_alive = off;   off = up(off + sizeof(uint32_t));                                   // (zeroed with the counters by rx_sampler_peer_begin)
     P.off_pendver = off; off = up(off + (size_t)rxs::PEND_SLOTS * N * sizeof(uint32_t));     // (zeroed with the counters by rx_sampler_peer_begin)
     P.off_nacc = off;    off = up(off + N * sizeof(int32_t));
     P.off_lnp = off;     off = up(off + N * sizeof(double));
@@ -1214,6 +1225,15 @@ int rx_sampler_peer_connect(rx_handle *h, const void *ipc_handles, void *const *
     }
     for (int r = 0; r < P.nranks; ++r)
         if (!P.base[r]) { h->err = "rx_sampler_peer_connect: a peer's replica is missing"; return RX_E_ARG; }
+    // the per-device registry of this run: which replicas live on THIS device (two handles of one process, ranks of a
+    // rehearsal squeezed onto one GPU).  A mapping whose device cannot be told counts as remote.
+    P.same_device = 0;
+    for (int r = 0; r < P.nranks; ++r) {
+        hipPointerAttribute_t at;
+        if (r == P.rank) { ++P.same_device; continue; }
+        if (hipPointerGetAttributes(&at, P.base[r]) == hipSuccess) { if (at.device == h->device) ++P.same_device; }
+        else (void)hipGetLastError();
+    }
     if (!P.d_bases) HIPCHK(h, hipMalloc(&P.d_bases, RX_MAX_RANKS * sizeof(char *)));
     HIPCHK(h, hipMemcpy(P.d_bases, P.base, RX_MAX_RANKS * sizeof(char *), hipMemcpyHostToDevice));
     P.connected = true;
@@ -1280,13 +1300,15 @@ int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, in
     A.ring = PEER_RING;
     A.chain = d_chain; A.chain_lnp = d_chain_lnp;
     A.timeout_ticks = h->sampler_timeout_ticks;
-    A.stats = h->stats_on ? h->d_stats : nullptr;
+    A.stall_ticks = h->sampler_stall_ticks;
+    A.alive = (uint32_t *)(P.own + P.off_alive);
+    A.stats = (h->stats_on && blocks * RXK_WAVES_PER_BLOCK <= rxs::RXS_STAT_SLOTS) ? h->d_stats : nullptr;   // (one slot per wavefront)
     A.speculate = (occ == 1) && h->speculation != 0;
     if (A.speculate) { A.pend = (double *)(P.own + P.off_pend); A.pend_version = (uint32_t *)(P.own + P.off_pendver); }
     // (nranks = 1 runs the very same kernel in its one-GPU form on the replica block)
     A.nranks = P.nranks; A.rank = P.rank; A.t_lo = (uint32_t)lo; A.t_n = (uint32_t)(hi - lo);
     A.peers = P.d_bases;
-    A.off_version = P.off_version; A.off_done = P.off_done; A.off_abort = P.off_abort;
+    A.off_version = P.off_version; A.off_done = P.off_done; A.off_abort = P.off_abort; A.off_alive = P.off_alive;
     A.off_lnp = P.off_lnp; A.off_nacc = P.off_nacc; A.off_hist = P.off_hist; A.off_pend = P.off_pend; A.off_pendver = P.off_pendver;
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RXK_WAVES_PER_BLOCK), 0, st, A);
@@ -1322,15 +1344,19 @@ int rx_sampler_stats(rx_handle *h, int enable, uint64_t *out6)
 {
     if (!h) return RX_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    if (!h->d_stats) { HIPCHK(h, hipMalloc(&h->d_stats, 8 * sizeof(unsigned long long))); HIPCHK(h, hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long))); }
+    const size_t nst = (size_t)8 * rxs::RXS_STAT_SLOTS;          // one block of 8 counters per wavefront of the grid
+    if (!h->d_stats) { HIPCHK(h, hipMalloc(&h->d_stats, nst * sizeof(unsigned long long))); HIPCHK(h, hipMemset(h->d_stats, 0, nst * sizeof(unsigned long long))); }
     if (h->in_flight) { HIPCHK(h, hipEventSynchronize(h->ev_done)); h->in_flight = false; }
     if (out6) {
-        unsigned long long v[8];
-        HIPCHK(h, hipMemcpy(v, h->d_stats, sizeof v, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> all(nst);
+        HIPCHK(h, hipMemcpy(all.data(), h->d_stats, nst * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long v[8] = {};
+        for (size_t w = 0; w < (size_t)rxs::RXS_STAT_SLOTS; ++w)
+            for (int i = 0; i < 8; ++i) v[i] += all[w * 8 + i];
         for (int i = 0; i < 6; ++i) out6[i] = v[i];
         h->last_spec[0] = v[6]; h->last_spec[1] = v[7];
     }
-    HIPCHK(h, hipMemset(h->d_stats, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->d_stats, 0, nst * sizeof(unsigned long long)));
     h->stats_on = enable ? 1 : 0;
     return 0;
 }
@@ -1353,6 +1379,46 @@ int rx_set_sampler_timeout_ms(rx_handle *h, double ms)
 {
     if (!h || !(ms >= 0.0) || ms > 3.6e6) return RX_E_ARG;
     h->sampler_timeout_ticks = (long long)(ms * 1e5);          // wall_clock64 ticks at 100 MHz
+    return 0;
+}
+
+int rx_set_sampler_stall_ms(rx_handle *h, double ms)
+{
+    if (!h || !(ms >= 0.0) || ms > 3.6e6) return RX_E_ARG;
+    h->sampler_stall_ticks = (long long)(ms * 1e5);
+    return 0;
+}
+
+int rx_sampler_peer_same_device(const rx_handle *h) { return h ? h->peer.same_device : RX_E_ARG; }
+
+int rx_sampler_peer_abort(rx_handle *h)
+{
+    if (!h) return RX_E_ARG;
+    rx_handle::Peer &P = h->peer;
+    if (!P.connected) { h->err = "rx_sampler_peer_abort: not connected"; return RX_E_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    // a stream of its own: the legacy default stream would wait for the very kernel this is meant to end
+    if (!h->ctl_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->ctl_stream, hipStreamNonBlocking));
+    static const uint32_t one = 1u;
+    for (int r = 0; r < P.nranks; ++r)
+        if (P.base[r]) HIPCHK(h, hipMemcpyAsync(P.base[r] + P.off_abort, &one, sizeof one, hipMemcpyHostToDevice, h->ctl_stream));
+    HIPCHK(h, hipStreamSynchronize(h->ctl_stream));
+    return 0;
+}
+
+int rx_peer_topology(int dev_a, int dev_b, int32_t *out3)
+{
+    if (!out3 || dev_a < 0 || dev_b < 0) return RX_E_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || dev_a >= n || dev_b >= n) { (void)hipGetLastError(); return RX_E_NODEVICE; }
+    out3[0] = 1; out3[1] = -1; out3[2] = 0;
+    if (dev_a == dev_b) return 0;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev_a, dev_b) != hipSuccess) { (void)hipGetLastError(); can = -1; }
+    out3[0] = can;
+    uint32_t type = 0, hops = 0;
+    if (hipExtGetLinkTypeAndHopCount(dev_a, dev_b, &type, &hops) == hipSuccess) { out3[1] = (int32_t)type; out3[2] = (int32_t)hops; }
+    else { (void)hipGetLastError(); out3[1] = -1; out3[2] = -1; }
     return 0;
 }
 

@@ -36,6 +36,15 @@ def _ip(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
+def peer_topology(dev_a, dev_b):
+    """(can_access_peer, link_type, hops) between two HIP devices (rx_peer_topology): 1 / 0 / -1, -1 = unknown."""
+    out = (C.c_int32 * 3)()
+    rc = _lib.load().rx_peer_topology(int(dev_a), int(dev_b), out)
+    if rc:
+        return None
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 class Engine:
     def __init__(self, molfile: str | None = None, species: str = "co", escapeProbGeom: str = "lvg",
                  deltav: float = 1.0, device: int = 0):
@@ -340,6 +349,17 @@ class Engine:
 
     def set_sampler_timeout_ms(self, ms):
         self._chk(self._L.rx_set_sampler_timeout_ms(self._h, float(ms)), "rx_set_sampler_timeout_ms")
+
+    def set_sampler_stall_ms(self, ms):
+        """No-progress watchdog of the dataflow kernels' waits (rx_set_sampler_stall_ms; default 100 ms)."""
+        self._chk(self._L.rx_set_sampler_stall_ms(self._h, float(ms)), "rx_set_sampler_stall_ms")
+
+    def sampler_peer_abort(self):
+        """Raise the abort word in every connected replica from the host: ends the peers' kernels at once."""
+        self._chk(self._L.rx_sampler_peer_abort(self._h), "rx_sampler_peer_abort")
+
+    def sampler_peer_same_device(self):
+        return int(self._L.rx_sampler_peer_same_device(self._h))
 
     def set_waves_per_simd(self, waves=0):
         """Scheduling of the solve launches: 0 = automatic, 1 = one wavefront per SIMD, 2 = two."""

@@ -90,10 +90,14 @@ def model_lvg(Jup, params, R=None):
 def lnprior(p, bounds, T_d=None, R=None):
     """emcee_radex.py:169-175; emcee_radex_2comp.py:199-234.  Evaluated by the engine's own prior
     (rx_lnprior_batch: the device function the fused lnprob uses; no solve is run): no second
-    statement of the branches on the host."""
+    statement of the branches on the host.  Works before init_radex() -- the handle is then created lazily with
+    the default background --; each call is a small GPU round trip, so batch bound checks of many points through
+    Engine.lnprior_batch rather than looping over this function."""
     R = R or globals()["R"]
     if R is None:
-        raise RuntimeError("call init_radex() first (the prior is evaluated by the engine)")
+        # the reference's lnprior needs no Radex handle (callers bound-check start points before they create one):
+        # the engine is created on first use -- on the GPU, like everything else; without one this raises EngineError
+        R = init_radex()
     p = np.asarray(p, dtype=np.float64)
     ncomp = p.size // 4
     one = np.ones(1)

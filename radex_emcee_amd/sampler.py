@@ -409,24 +409,29 @@ class DeviceEnsembleSampler:
     log_prob_fn  a host function (numpy in, numpy out): CPU restatement of the same kernels (checker)
     nens      independent ensembles advancing together (BASELINE config 3: one per source);
               ens_src[nens] = source slot of each (default: slot 0 for all)
-    schedule  "dataflow" (default): the chain as one persistent kernel (per GPU) whose tasks start when
+    schedule  "dataflow" (the default on ONE GPU): the chain as one persistent kernel whose tasks start when
               their two input walkers are final -- or earlier, on the newest final position of a walker that is
               still being updated (Engine.set_sampler_speculation; the same chain either way);
               "halfsteps": one propose / solve / accept round per half-step
     group     torch.distributed group, one process per GPU: the proposals of every half-step are dealt out
               in contiguous blocks, one per rank (the reference's Pool.map over walkers,
-              emcee_radex.py:480-488).  schedule="dataflow": every rank runs its block's tasks in its own
-              persistent kernel and publishes each result into the replicas of ALL ranks with peer writes
-              over xGMI (rx_sampler_peer_*: IPC-mapped fine-grained memory, no collective, no barrier per
-              half-step, no host in the loop; two host barriers per run_mcmc call); it falls back to
-              "halfsteps" -- block evaluation per rank, ONE all_gather of log-probabilities (RCCL on GPUs)
-              before the accept step, SURVEY 8e's literal form and the checker of the peer path -- when
-              the replicas cannot be shared (IPC unavailable).  Positions and the counter-based random
-              stream are replicated either way, so the proposals need no exchange and every rank accepts
+              emcee_radex.py:480-488).  The DEFAULT with a group is "halfsteps": block evaluation per rank,
+              ONE all_gather of log-probabilities (RCCL on GPUs) before the accept step -- north_star's and
+              SURVEY 8e's literal form.  schedule="dataflow" with a group is opt-in: every rank runs its
+              block's tasks in its own persistent kernel and publishes each result into the replicas of ALL
+              ranks with peer writes over xGMI (rx_sampler_peer_*: IPC-mapped fine-grained memory, no
+              collective, no barrier per half-step, no host in the loop).  That path has only ever run with
+              its ranks on ONE physical GPU, so a sampler does not trust it blindly: its first run_mcmc call
+              first advances `verify_peer_steps` steps (default 8) under BOTH schedules from the same state
+              and compares positions, log-probabilities and acceptance counts bit for bit on every rank
+              (`peer_verified`, `peer_verify_detail`); any difference, on any rank, and all ranks use
+              "halfsteps" from then on.  It also falls back when the replicas cannot be shared (IPC
+              unavailable) or a run is abandoned (watchdog).  Positions and the counter-based random stream
+              are replicated either way, so the proposals need no exchange and every rank accepts
               identically.  The chain is the one-GPU chain, bit for bit, under both schedules."""
 
     def __init__(self, nwalkers, ndim, engine=None, log_prob_fn=None, nens=1, ens_src=None, a=2.0, seed=0,
-                 group=None, sharded=None, schedule="dataflow"):
+                 group=None, sharded=None, schedule=None, verify_peer_steps=8):
         import torch
         if nwalkers < 2 * ndim:
             raise ValueError("The number of walkers needs to be at least twice the dimension "
@@ -473,9 +478,15 @@ class DeviceEnsembleSampler:
         # schedule (single GPU, engine backend): "dataflow" = one persistent kernel, every proposal starts
         # as soon as the two walkers it reads are final (rx_sampler_run_async_device); "halfsteps" = propose /
         # solve / accept launches per half-step (rx_sampler_run_device).  The chains are bit-identical.
+        if schedule is None:              # the peer-write path across GPUs is opt-in (see the class docstring)
+            schedule = "halfsteps" if self._sharded else "dataflow"
         if schedule not in ("dataflow", "halfsteps"):
             raise ValueError("schedule must be 'dataflow' or 'halfsteps'")
         self.schedule = schedule
+        self.verify_peer_steps = int(verify_peer_steps)
+        self.peer_verified = None         # None: not checked (yet); True / False: the first peer run against the half-step schedule
+        self.peer_verify_detail = None
+        self.schedule_reason = None       # why the last run_mcmc used the schedule it used
         self.peer_state = None            # None: not tried yet; True: replicas connected; str: why not (halfsteps then)
         self.last_schedule = None         # what the last run_mcmc actually used
         self.fallback = True              # dataflow run abandoned (timeout) -> repeat it per half-step
@@ -579,11 +590,9 @@ class DeviceEnsembleSampler:
         bad = [i for i, (_, e, _) in enumerate(infos) if e]
         if not bad:
             # ranks that share one GPU (rehearsals on a one-GPU box) must all be resident at once: split the CUs
-            nshare = sum(1 for (_, _, m) in infos if m == me)
-            if nshare > 1:
-                import torch
-                ncu = torch.cuda.get_device_properties(self.coords.device).multi_processor_count
-                eng.set_sampler_grid_limit(max(1, ncu // nshare))
+            # (the library counts the replicas that live on its own device itself -- rx_sampler_peer_same_device -- and
+            # splits the compute units; an explicit limit of an earlier set-up must not outlive it)
+            eng.set_sampler_grid_limit(0)
             try:
                 eng.sampler_peer_connect(ipc_handles=[h for (h, _, _) in infos])
             except EngineError as exc:
@@ -608,30 +617,61 @@ class DeviceEnsembleSampler:
         eng._peer_owner = self            # one replica block per handle: another sampler's set-up replaces it
         return True
 
+    def _agree(self, err):
+        """Collective in place of a barrier: every rank contributes None or what went wrong on it and learns about all
+        of them, so that one rank's failure raises (or falls back) on ALL ranks instead of leaving the others in a
+        barrier until the process-group timeout.  Returns [(rank, message)] of the ranks that failed."""
+        errs = self._gather_objects(err)
+        return [(r, e) for r, e in enumerate(errs) if e]
+
     def _run_peer(self, nsteps, chain, chain_lnp):
         """One run_mcmc call under the peer-write dataflow schedule.  Returns False when a task on some rank gave
-        up waiting (every rank sees it): the caller repeats the run per half-step."""
-        import torch
+        up waiting (every rank sees it): the caller repeats the run per half-step.  An error on one rank (HIP,
+        state) is raised on EVERY rank."""
+        import os
         from .engine import EngineError, RX_E_TIMEOUT
         eng, dev = self.engine, self.coords.device
-        eng.sampler_peer_begin(self.coords, self.lnp, self.naccept)
-        self._barrier()                               # every replica is seeded: peers may write into it
-        eng.sampler_peer_run(self.a, self.seed, self.step_counter, nsteps, dev, chain, chain_lnp, ens_src=self.ens_src)
-        timed_out = False
+        err = None
         try:
-            eng.sampler_wait(dev)
-        except EngineError as exc:                    # (the one-GPU flag; the replicas' abort word is read by finish)
-            if exc.rc != RX_E_TIMEOUT:
-                raise
-            timed_out = True
-        self._barrier()                               # every peer has finished: this rank's replica is complete
+            eng.sampler_peer_begin(self.coords, self.lnp, self.naccept)
+        except EngineError as exc:
+            err = "sampler_peer_begin: %s" % exc
+        bad = self._agree(err)                        # (= barrier) every replica is seeded: peers may write into it
+        if bad:
+            raise EngineError("multi-GPU dataflow sampler, rank %d: %s" % bad[0])
+        err, timed_out = None, False
+        try:
+            if os.environ.get("RX_TEST_INJECT_PEER_ERROR") == str(self.rank):     # (tests: a launch failure on one rank)
+                raise EngineError("injected launch failure (RX_TEST_INJECT_PEER_ERROR)", -5)
+            eng.sampler_peer_run(self.a, self.seed, self.step_counter, nsteps, dev, chain, chain_lnp, ens_src=self.ens_src)
+        except EngineError as exc:
+            err = "sampler_peer_run: %s" % exc
+            try:
+                eng.sampler_peer_abort()              # the peers' kernels wait for this rank's tasks: end them now
+            except EngineError:
+                pass
+        if err is None:
+            try:
+                eng.sampler_wait(dev)
+            except EngineError as exc:                # (the one-GPU flag; the replicas' abort word is read by finish)
+                if exc.rc == RX_E_TIMEOUT:
+                    timed_out = True
+                else:
+                    err = "sampler_wait: %s" % exc
+        bad = self._agree(err)                        # (= barrier) every peer has finished: this rank's replica is complete
+        if bad:
+            raise EngineError("multi-GPU dataflow sampler, rank %d: %s" % bad[0])
         try:
             eng.sampler_peer_finish(self.coords, self.lnp, self.naccept)
         except EngineError as exc:
             if exc.rc != RX_E_TIMEOUT:
-                raise
+                err = "sampler_peer_finish: %s" % exc
             timed_out = True
-        if timed_out:
+        flags = self._gather_objects((err, timed_out))
+        bad = [(r, e) for r, (e, _) in enumerate(flags) if e]
+        if bad:
+            raise EngineError("multi-GPU dataflow sampler, rank %d: %s" % bad[0])
+        if any(t for (_, t) in flags):
             return False
         if chain is not None and self.world > 1:      # each rank wrote the rows of the walkers it updated (others zero)
             for t in (chain, chain_lnp):
@@ -642,6 +682,45 @@ class DeviceEnsembleSampler:
                 else:
                     self._dist.all_reduce(t, group=self.group)
         return True
+
+    def _halfsteps(self, nsteps, chain, chain_lnp):
+        """nsteps steps, one propose / evaluate (sharded when there is a group) / accept round per half-step."""
+        for s in range(nsteps):
+            step = self.step_counter + s
+            for split in range(2):
+                self.backend.propose(self, step, split)
+                lnp_q = self._evaluate(self.q, self.qsrc)
+                self.backend.accept(self, step, split, lnp_q)
+            if chain is not None:
+                chain[s].copy_(self.coords)
+                chain_lnp[s].copy_(self.lnp)
+
+    def _verify_peer(self):
+        """The peer-write path has never crossed a device boundary in a test: before a sampler
+        relies on it, the first steps are advanced under BOTH schedules from the same state and compared bit for bit,
+        on every rank.  Collective; returns True when every rank saw identical states.  The sampler's own state and
+        step counter are left as they were (the random stream is counter based: nothing is consumed)."""
+        import hashlib
+        import torch
+        k = self.verify_peer_steps
+        start = (self.coords.clone(), self.lnp.clone(), self.naccept.clone())
+        ok_run = self._run_peer(k, None, None)
+        a = tuple(t.clone() for t in (self.coords, self.lnp, self.naccept))
+        for dst, src in zip((self.coords, self.lnp, self.naccept), start):
+            dst.copy_(src)
+        self._halfsteps(k, None, None)
+        b = (self.coords, self.lnp, self.naccept)
+        bits = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t          # bit for bit, NaN or not
+        same = bool(ok_run) and all(torch.equal(bits(x), bits(y)) for x, y in zip(a, b))
+        digest = hashlib.sha1(b"".join(t.cpu().numpy().tobytes() for t in b)).hexdigest()[:16]
+        for dst, src in zip((self.coords, self.lnp, self.naccept), start):
+            dst.copy_(src)
+        res = self._gather_objects((same, bool(ok_run), digest))
+        allsame = all(r[0] for r in res) and len({r[2] for r in res}) == 1
+        self.peer_verified = bool(allsame)
+        self.peer_verify_detail = {"steps": k, "ranks_identical": [bool(r[0]) for r in res], "peer_run_completed": [bool(r[1]) for r in res],
+                                   "halfstep_state_sha1": [r[2] for r in res]}
+        return self.peer_verified
 
     # --- sampling ---------------------------------------------------------------------------------------
     def run_mcmc(self, initial_state, nsteps, progress=False, store=True):
@@ -677,11 +756,33 @@ class DeviceEnsembleSampler:
             chain = alloc(nsteps, self.N, self.ndim, dtype=torch.float64, device=self.coords.device)
             chain_lnp = alloc(nsteps, self.N, dtype=torch.float64, device=self.coords.device)
         self.last_schedule = "halfsteps"
+        self.schedule_reason = ("requested" if self.schedule == "halfsteps" else
+                                "time_solves" if self.time_solves else
+                                ("peer replicas unavailable: %s" % self.peer_state) if isinstance(self.peer_state, str) else None)
+        if peer and self.peer_verified is None and self.verify_peer_steps > 0 and self.world > 1:
+            if not self._verify_peer():
+                self.peer_state = "the peer-write chain differed from the half-step chain in the first %d steps (%s)" % (
+                    self.verify_peer_steps, self.peer_verify_detail)
+                self.schedule_reason = self.peer_state
+                if self.rank == 0:
+                    import warnings
+                    warnings.warn("multi-GPU dataflow sampler: %s; half-steps + all_gather instead" % self.peer_state)
+                try:
+                    self.engine.sampler_peer_close()
+                except EngineError:
+                    pass
+                peer = False
+                if chain is not None:
+                    chain = torch.empty_like(chain)
+                    chain_lnp = torch.empty_like(chain_lnp)
         if peer:
             start = (self.coords.clone(), self.lnp.clone(), self.naccept.clone())
             if self._run_peer(nsteps, chain, chain_lnp):
                 self.last_schedule = "dataflow-peer"
+                self.schedule_reason = "requested" + ("" if self.peer_verified is None else
+                                                      "; first %d steps identical to the half-step schedule on every rank" % self.verify_peer_steps)
             else:
+                self.schedule_reason = "the peer-write run was abandoned (watchdog on some rank): repeated per half-step"
                 if not self.fallback:
                     raise EngineError("multi-GPU dataflow sampler: a task waited longer than the timeout", RX_E_TIMEOUT)
                 import warnings
@@ -707,6 +808,7 @@ class DeviceEnsembleSampler:
                 # state this call started with
                 import warnings
                 warnings.warn("dataflow sampler abandoned its run (%s); repeating it per half-step" % exc)
+                self.schedule_reason = "the dataflow run was abandoned (%s): repeated per half-step" % exc
                 self.coords.copy_(start[0]); self.lnp.copy_(start[1]); self.naccept.copy_(start[2])
                 dataflow = False
         if peer:
@@ -720,15 +822,9 @@ class DeviceEnsembleSampler:
                 self.coords, self.lnp, self.naccept, chain, chain_lnp, ens_src=self.ens_src,
                 time_solves=self.time_solves)
         else:
-            for s in range(nsteps):
-                step = self.step_counter + s
-                for split in range(2):
-                    self.backend.propose(self, step, split)
-                    lnp_q = self._evaluate(self.q, self.qsrc)
-                    self.backend.accept(self, step, split, lnp_q)
-                if chain is not None:
-                    chain[s].copy_(self.coords)
-                    chain_lnp[s].copy_(self.lnp)
+            self._halfsteps(nsteps, chain, chain_lnp)
+        if self.schedule_reason is None:
+            self.schedule_reason = "requested"
         self.step_counter += nsteps
         self.iteration += nsteps
         if chain is not None:

@@ -44,7 +44,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert sh["scaling"] == "strong" and sh["walker_steps_per_s"] > 0
         assert sh["one_gpu_dataflow"]["walker_steps_per_s"] > 0 and sh["speedup_vs_1gpu_dataflow"] == 1.0
     smp = d["sampler"]
-    assert smp["half_step_schedule"]["same_chain_as_dataflow"] is True        # (speed ratios are bench output, not asserted)
+    assert smp["half_step_schedule"]["same_chain_as_dataflow"] is True
+    # a loose speed guard: the dataflow schedule is there to beat the half-step schedule (2.2 M against 0.43 M walker-steps/s);
+    # a regression that loses even that fails here
+    assert smp["walker_steps_per_s"] > smp["half_step_schedule"]["walker_steps_per_s"]
     # round 3: the fp64-VALU roofline inside the parsed object, the prior-box ensemble of SURVEY 8(d) in the sampler
     # with the kernel's own counters, BASELINE configs[0] through the reference's call site
     fv = r["fp64_valu"]
@@ -57,6 +60,17 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert pb["without_head_starts"]["same_chain"] is True and pb["without_head_starts"]["ms_per_step"] > 0
     c0 = d["config0"]
     assert c0["wall_s"] > 0 and c0["schedule"] == "dataflow" and 0.05 < c0["acceptance"] < 0.95
+    # round 4: evaluations counted the way SURVEY 8(d) defines them (a proposal that reaches the solver), the sampler's number
+    # at the top level of the parsed line, the preflight block
+    assert 0.0 <= pb["proposals_outside_the_prior"] < 0.5
+    assert abs(pb["evals_reaching_solver_per_s"] - pb["walker_steps_per_s"] * (1.0 - pb["proposals_outside_the_prior"])) < 2e-3 * pb["walker_steps_per_s"]
+    assert 0.0 < pb["useful_fp64_frac"] < 1.0 and "evals_reaching_solver_per_s" in pb["unit"]
+    assert d["walker_steps_per_s_1024"] == pb["walker_steps_per_s"] and d["evals_reaching_solver_per_s_1024"] == pb["evals_reaching_solver_per_s"]
+    for blk in (c0, c3["sampler"], smp["kernel_counters"], d["sharded"]["config4"]["one_gpu_dataflow"], d["sharded"]["config5"]["one_gpu_dataflow"]):
+        assert blk["evals_reaching_solver_per_s"] > 0 and 0.0 < blk["useful_fp64_frac"] < 1.0, blk
+    pre = d["preflight"]
+    assert pre["world_size_counted_by_all_reduce"] == 1 and pre["devices_visible"] >= 1
+    assert pre["peer_access"][0][0]["can_access_peer"] == 1
     # traffic comes from the committed PMC summary and only if it was measured on THIS kernel source
     tr = r["traffic"]
     assert tr is None or tr["bytes_per_launch"] is None or tr["bytes_per_launch"] > r["algorithmic_bytes_per_launch"]
@@ -75,12 +89,29 @@ def test_bench_gpus_2_starts_its_own_ranks_on_a_shared_gpu():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert "all_gather_into_tensor(2048 x f64)" in d["config"]["collective"]
-    for name in ("config4", "config5"):
+    # the headline is BASELINE's metric: the SAME 1024 walkers, strong scaled (512 per rank), ONE all_gather inside the step
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert d["config"]["walkers"] == 1024 and d["config"]["walkers_per_gpu"] == 512
+    assert "all_gather_into_tensor(1024 x f64)" in d["config"]["collective"]
+    assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    # the weak-scaled pass of earlier rounds: an extra key, not the value
+    assert d["weak"]["scaling"] == "weak" and d["weak"]["walkers_total"] == 2048 and d["weak"]["value"] > 0
+    # preflight: what the run found, and per shape the schedule that ACTUALLY ran and why
+    pre = d["preflight"]
+    assert pre["world_size_counted_by_all_reduce"] == 2 and pre["ranks_share_one_gpu"] is True and pre["backend"] == "gloo"
+    assert pre["peer_access"][0][0]["can_access_peer"] == 1
+    for name in ("config2", "config4", "config5"):
+        sc = pre["schedules"][name]
+        assert sc["ran"] == "dataflow-peer" and sc["peer_verified_against_halfsteps"] is True, sc
+        assert "identical" in sc["why"] and sc["replicas_on_this_device"] == 2
+    c2 = d["sharded"]["config2"]                       # BASELINE configs[1] as ONE ensemble in the sampler, strong scaled
+    assert c2["walkers"] == 1024 and c2["proposals_per_rank"] == 256
+    for name in ("config2", "config4", "config5"):
         sh = d["sharded"][name]
         assert sh["n_gpus"] == 2 and sh["one_gpu_dataflow"]["walker_steps_per_s"] > 0
         m = sh["multi_gpu_dataflow"]
         assert m["schedule"].startswith("dataflow-peer"), m["schedule"]
-        assert m["ranks_share_one_gpu"] is True and m["speedup_vs_1gpu_dataflow"] > 0
-        assert sh["multi_gpu_halfsteps_allgather"]["speedup_vs_1gpu_dataflow"] > 0
+        assert m["ranks_share_one_gpu"] is True and m["speedup_vs_1gpu_dataflow"] > 0 and m["speedup_vs_1gpu"] > 0
+        assert m["schedule_actually_run"] == "dataflow-peer"
+        assert sh["multi_gpu_halfsteps_allgather"]["speedup_vs_1gpu"] > 0

@@ -142,7 +142,8 @@ def test_peer_dataflow_one_rank_group(co_path, mol):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
-        d = DeviceEnsembleSampler(256, 4, engine=e, seed=9, group=dist.group.WORLD)
+        assert DeviceEnsembleSampler(256, 4, engine=e, seed=9, group=dist.group.WORLD).schedule == "halfsteps"   # the default with a group
+        d = DeviceEnsembleSampler(256, 4, engine=e, seed=9, group=dist.group.WORLD, schedule="dataflow")
         st = d.run_mcmc(p0, 6)
         assert d.last_schedule == "dataflow-peer" and d.peer_state is True
         assert np.array_equal(st.coords, st_ref.coords) and np.array_equal(d.get_chain(), ref.get_chain())
@@ -160,6 +161,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1])
 rank, world, port, out, shape, nw, nsteps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6], int(sys.argv[7]), int(sys.argv[8])
+import json
 import torch
 import torch.distributed as dist
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -184,12 +186,20 @@ else:
     e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"], 2, cfg["T_d"])
     tf = e.model_flux_batch(cfg["truth"][None, :])[0]
     e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"], 2, cfg["T_d"])
-d = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5, group=dist.group.WORLD, nens=nens, ens_src=ens_src)
+d = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5, group=dist.group.WORLD, nens=nens, ens_src=ens_src, schedule="dataflow")
 d.fallback = False                                     # a timeout is a failure here, not a silent half-step run
-st = d.run_mcmc(cfg["walkers"], nsteps)
-st = d.run_mcmc(st, 3)                                 # a second call: replica re-seeded, step counter continues
+from radex_emcee_amd.engine import EngineError
+try:
+    st = d.run_mcmc(cfg["walkers"], nsteps)
+    st = d.run_mcmc(st, 3)                                 # a second call: replica re-seeded, step counter continues
+except EngineError as exc:                              # (the injected-failure test: every rank must get here, none may hang)
+    open(out + "/peer_%d.err" % rank, "w").write(str(exc))
+    dist.destroy_process_group()
+    sys.exit(3)
 np.savez(out + "/peer_%d.npz" % rank, coords=st.coords, lnp=st.log_prob, chain=d.get_chain(), chain_lnp=d.get_log_prob(),
-         acc=d.acceptance_fraction, schedule=np.array(d.last_schedule), peer=np.array(str(d.peer_state)))
+         acc=d.acceptance_fraction, schedule=np.array(d.last_schedule), peer=np.array(str(d.peer_state)),
+         verified=np.array(str(d.peer_verified)), detail=np.array(json.dumps(d.peer_verify_detail)),
+         reason=np.array(str(d.schedule_reason)), same_device=np.array(e.sampler_peer_same_device() if d.peer_state is True else -1))
 dist.barrier(); dist.destroy_process_group()
 e.close()
 '''
@@ -232,6 +242,10 @@ def test_peer_dataflow_two_processes_ipc(co_path, mol, tmp_path, shape, nw, nste
     for r in range(2):
         z = np.load(tmp_path / ("peer_%d.npz" % r))
         assert str(z["schedule"]) == "dataflow-peer", (str(z["schedule"]), str(z["peer"]))
+        # the sampler checked its first steps against the half-step schedule on both ranks before it relied on the peer path,
+        # and the library saw that both replicas live on ONE device (it splits the compute units by itself then)
+        assert str(z["verified"]) == "True" and "identical" in str(z["reason"]), (str(z["verified"]), str(z["detail"]))
+        assert int(z["same_device"]) == 2
         assert np.array_equal(z["coords"], st.coords) and np.array_equal(z["lnp"], st.log_prob)
         assert np.array_equal(z["chain"], ref.get_chain()) and np.array_equal(z["chain_lnp"], ref.get_log_prob())
         assert np.array_equal(z["acc"], ref.acceptance_fraction)
@@ -262,3 +276,67 @@ def test_peer_unavailable_falls_back_to_halfsteps_on_every_rank(co_path, mol, tm
         assert str(z["schedule"]) == "halfsteps" and "RX_NO_PEER" in str(z["peer"])
         assert np.array_equal(z["coords"], st.coords) and np.array_equal(z["chain"], ref.get_chain())
     e.close()
+
+
+def test_peer_error_on_one_rank_raises_on_every_rank(co_path, mol, tmp_path):
+    """A launch failure on rank 1 (injected: RX_TEST_INJECT_PEER_ERROR) must not leave rank 0 in a barrier until the
+    process-group timeout: rank 1 raises the abort word in every replica from the host (rx_sampler_peer_abort), rank 0's
+    kernel drains, the ranks exchange what happened and BOTH raise EngineError -- within seconds."""
+    import time
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "peer_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RX_TEST_INJECT_PEER_ERROR="1")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-W", "ignore", str(script), ROOT, str(r), "2", str(port), str(tmp_path), "config2",
+                               "256", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung behind the failing one")
+    assert [p.returncode for p in procs] == [3, 3], "\n".join(outs)
+    for r in range(2):
+        msg = open(tmp_path / ("peer_%d.err" % r)).read()
+        assert "rank 1" in msg and "injected launch failure" in msg, msg
+    assert time.time() - t0 < 200
+
+
+def test_two_engines_sample_concurrently_on_one_gpu(co_path, mol):
+    """Two independent fits on ONE GPU (two handles, two streams, both persistent dataflow kernels in flight together):
+    a task only waits for tasks of its own launch, so neither can starve the other -- both chains are the chains the
+    engines produce alone, and nobody runs into the watchdog (a run that did would have been repeated per half-step)."""
+    import torch
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler, State
+    engs = [Engine(co_path), Engine(co_path)]
+    p0s, refs = [], []
+    for k, e in enumerate(engs):
+        p0, _ = _setup(e, mol, "config2", 1024)
+        p0s.append(p0 + 1e-3 * k)
+        r = DeviceEnsembleSampler(1024, 4, engine=e, seed=21 + k)
+        refs.append((r.run_mcmc(p0s[k], 30), r))
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in engs]
+    smp = [DeviceEnsembleSampler(1024, 4, engine=e, seed=21 + k) for k, e in enumerate(engs)]
+    chains, lnps = [], []
+    for k, (e, d) in enumerate(zip(engs, smp)):                # both launches are enqueued before either is waited for
+        d.fallback = False
+        d.coords.copy_(torch.from_numpy(p0s[k]))
+        d.lnp.copy_(d.compute_log_prob(p0s[k]))
+        chains.append(torch.empty(30, 1024, 4, dtype=torch.float64, device=dev))
+        lnps.append(torch.empty(30, 1024, dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    for k, (e, d) in enumerate(zip(engs, smp)):
+        e.sampler_run_async_torch(1, 1024, 1, 2.0, 21 + k, 0, 30, d.coords, d.lnp, d.naccept, chains[k], lnps[k],
+                                  stream=streams[k].cuda_stream)
+    for k, e in enumerate(engs):
+        e.sampler_wait(dev, stream=streams[k].cuda_stream)     # raises RX_E_TIMEOUT if a task ran into the watchdog
+    for k, d in enumerate(smp):
+        st_ref, r = refs[k]
+        assert np.array_equal(d.coords.cpu().numpy(), st_ref.coords) and np.array_equal(d.lnp.cpu().numpy(), st_ref.log_prob)
+        assert np.array_equal(chains[k].cpu().numpy(), r.get_chain())
+    for e in engs:
+        e.close()

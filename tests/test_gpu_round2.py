@@ -42,9 +42,11 @@ def _report(tag, lnp, ref, st):
     ok, mx = fin & (st == RX_OK), fin & (st == RX_MAXITER)
     dok = _rel(lnp[ok], ref[ok]).max() if ok.any() else 0.0
     dmx = _rel(lnp[mx], ref[mx]) if mx.any() else np.zeros(1)
-    print("\n[%s] %d walkers: converged %d (max rel dev of lnprob %.2e); maxiter %d (max %.2e, "
-          "99th pct %.2e, above 1e-4: %d)" % (tag, len(ref), ok.sum(), dok, mx.sum(), dmx.max(),
-                                              np.percentile(dmx, 99), int((dmx > 1e-4).sum())))
+    # (the distribution goes into the pytest log -- GPUTEST carries it every round: the asserted ceilings of the maxiter tier
+    # are kept close to what is observed, so that a regression of an order of magnitude fails)
+    print("\n[%s] %d walkers: converged %d (max rel dev of lnprob %.2e); maxiter %d: 99th pct %.2e, 99.9th pct %.2e, "
+          "max %.2e, above 1e-4: %d" % (tag, len(ref), ok.sum(), dok, mx.sum(), np.percentile(dmx, 99),
+                                        np.percentile(dmx, 99.9), dmx.max(), int((dmx > 1e-4).sum())))
     return dok, dmx
 
 
@@ -87,7 +89,7 @@ def test_config3_sixteen_sources_one_launch(eng, mol):
         assert _rel(lnp[sl][okm], rl[okm]).max() < 1e-6, s["name"]
         mx = fin & (rst == RX_MAXITER)
         if mx.any():
-            assert _rel(lnp[sl][mx], rl[mx]).max() < 1e-3, s["name"]
+            assert _rel(lnp[sl][mx], rl[mx]).max() < 5e-4, s["name"]
         # fluxes of this source's walkers (its own line list) against the oracle
         flux, fst, fnit = eng.model_flux_batch(P[sl], src=s["slot"], return_info=True)
         rf, rfst, _ = O.model_flux_batch(mol, srcs[k], P[sl], nthreads=NTH)
@@ -117,7 +119,7 @@ def test_two_component_issue_order_against_oracle(eng, mol):
     fin = np.isfinite(rl)
     assert np.array_equal(fin, np.isfinite(lnp)) and fin.sum() > 2000
     dok, dmx = _report("2-comp, 4096 walkers, issue order on", lnp, rl, rst)
-    assert dok < 1e-6 and dmx.max() < 1e-3
+    assert dok < 1e-6 and dmx.max() < 5e-4
     flux = eng.model_flux_batch(W[2040:2300])
     rf = O.model_flux_batch(mol, src, W[2040:2300], nthreads=NTH)[0]
     ok, d = _flux_ok(flux, rf, W[2040:2300], cfg["tbg"], mol, ncomp=2)
@@ -140,12 +142,13 @@ def test_full_width_parity_config5(eng, mol):
     assert np.array_equal(fin, np.isfinite(lnp))
     dok, dmx = _report("config 5, 65536 walkers", lnp, rl, rst)
     assert dok < 1e-4
-    assert np.percentile(dmx, 99) < 1e-4 and dmx.max() < 1e-2
+    # maxiter tier (observed over 262 144 walkers: worst 1.5e-4, 99.9th percentile 9.5e-7; profiles/r3_big_parity_262144.txt)
+    assert np.percentile(dmx, 99.9) <= 1e-4 and dmx.max() < 1e-3
     # the fluxes themselves, at the same width (north_star's bar is stated on flux).  Two tiers, as README states
     # them: walkers that converge -- 1e-4 relative (+ the background floor) on every line; walkers that stop at
     # maxiter = 200 never settle and amplify round-off over their 200 iterations (in the reference their answer
     # even depends on the worker's previous walker, emcee/pyradex/core.py:896): 99.9 % of their fluxes within 1e-4,
-    # none beyond 1e-2.
+    # none beyond 1e-3 (observed worst: 1.6e-5).
     flux, fst, _ = eng.model_flux_batch(cfg["walkers"], return_info=True)
     rflux, rfst, _ = O.model_flux_batch(mol, src, cfg["walkers"], nthreads=NTH)
     assert np.array_equal(fst, rfst)
@@ -158,9 +161,11 @@ def test_full_width_parity_config5(eng, mol):
     assert ok[conv].all(), "converged walkers beyond 1e-4 on flux: %d" % int((~ok[conv]).any(axis=1).sum())
     rel = d[mx] / np.maximum(np.abs(rflux[mx]), 1e-300)
     frac_ok = ok[mx].mean()
-    print("maxiter walkers: %d, flux entries within tolerance %.5f, worst relative deviation %.2e"
-          % (int(mx.sum()), frac_ok, float(rel[~ok[mx]].max()) if (~ok[mx]).any() else 0.0))
-    assert frac_ok >= 0.999 and (ok[mx] | (rel < 1e-2)).all()
+    relw = np.where(ok[mx], 0.0, rel)                                # (entries inside the tolerance or under the floor count as 0)
+    print("maxiter walkers: %d, flux entries within tolerance %.5f; relative deviation of all their flux entries: 99th pct %.2e, "
+          "99.9th pct %.2e, max %.2e; worst beyond tolerance %.2e"
+          % (int(mx.sum()), frac_ok, np.percentile(rel, 99), np.percentile(rel, 99.9), float(rel.max()), float(relw.max())))
+    assert frac_ok >= 0.999 and (ok[mx] | (rel < 1e-3)).all()
 
 
 def test_full_width_parity_config4(eng, mol):
@@ -173,7 +178,7 @@ def test_full_width_parity_config4(eng, mol):
     fin = np.isfinite(rl)
     assert np.array_equal(fin, np.isfinite(lnp)) and fin.sum() > 1000
     dok, dmx = _report("config 4, 2048 two-component walkers", lnp, rl, rst)
-    assert dok < 1e-6 and dmx.max() < 1e-3
+    assert dok < 1e-6 and dmx.max() < 5e-4
 
 
 def test_device_index_is_validated_not_substituted(co_path, mol):
@@ -465,3 +470,27 @@ def test_reference_kats_with_a_real_co_dat_on_the_gpu():
     RR.temperature = 25
     RR.run_radex()
     np.testing.assert_almost_equal(RR.tex[0], 37.88, decimal=1)
+
+
+def test_one_and_two_wavefronts_per_simd_agree_bit_for_bit(eng, mol):
+    """The "same chain bit for bit across schedules and ranks" claims need the two builds of the solve to give the SAME bits:
+    a rank's block is nq / nranks tasks, so a rank can run the one-wavefront-per-SIMD build (its exp / log constants held
+    in registers: exp_neg, rx_log_t<HELD>) where the one-GPU run of the same ensemble uses the two-wavefront build (OCML
+    exp).  Prior-box walkers including ones that run into maxiter and both escape-probability branches; then a short
+    dataflow chain under each."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler
+    cfg = workloads.config2(6144, seed=4242)
+    _truth_source(eng, mol, cfg)
+    res = []
+    for occ in (1, 2):
+        eng.set_waves_per_simd(occ)
+        lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True)
+        flux = eng.model_flux_batch(cfg["walkers"][:1024])
+        d = DeviceEnsembleSampler(1024, 4, engine=eng, seed=31)
+        stt = d.run_mcmc(cfg["walkers"][:1024], 6)
+        res.append((lnp, st, nit, flux, stt.coords, stt.log_prob, d.get_chain()))
+    eng.set_waves_per_simd(0)
+    assert (res[0][1] == RX_MAXITER).sum() >= 20 and (res[0][1] == RX_OK).sum() > 4000
+    assert (res[0][2] > 40).any() and (res[0][2] < 20).any()
+    for a, b, what in zip(res[0], res[1], ("lnprob", "status", "niter", "flux", "chain end", "chain lnp", "chain")):
+        assert np.array_equal(a, b, equal_nan=True), what

@@ -210,6 +210,12 @@ from radex_emcee_amd.sampler import State
 st = d.run_mcmc(State(p0, lnp0), 25)
 np.save(sys.argv[5] + "/dcoords_%d.npy" % rank, st.coords)
 np.save(sys.argv[5] + "/dcalls_%d.npy" % rank, np.array(calls))
+# with a group the default schedule is half-steps + all_gather (the peer-write dataflow path across GPUs is opt-in)
+assert d.schedule == "halfsteps" and d.last_schedule == "halfsteps" and d.schedule_reason == "requested"
+# the collective that replaces the bare barriers of the peer protocol: one rank's failure is seen by EVERY rank
+assert d._agree(None) == []
+bad = d._agree("boom on rank 1" if rank == 1 else None)
+assert bad == [(1, "boom on rank 1")], bad
 # tensor form of ShardedLogProb: block in, block out, collective on tensors
 def lp_t(P, out):
     out.copy_(-0.5 * ((P - torch.from_numpy(mu)) ** 2).sum(1))
