@@ -643,7 +643,8 @@ class DeviceEnsembleSampler:
         try:
             if os.environ.get("RX_TEST_INJECT_PEER_ERROR") == str(self.rank):     # (tests: a launch failure on one rank)
                 raise EngineError("injected launch failure (RX_TEST_INJECT_PEER_ERROR)", -5)
-            eng.sampler_peer_run(self.a, self.seed, self.step_counter, nsteps, dev, chain, chain_lnp, ens_src=self.ens_src)
+            if os.environ.get("RX_TEST_INJECT_PEER_STALL") != str(self.rank):     # (tests: a rank whose kernel never starts)
+                eng.sampler_peer_run(self.a, self.seed, self.step_counter, nsteps, dev, chain, chain_lnp, ens_src=self.ens_src)
         except EngineError as exc:
             err = "sampler_peer_run: %s" % exc
             try:

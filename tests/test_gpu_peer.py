@@ -188,6 +188,10 @@ else:
     e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"], 2, cfg["T_d"])
 d = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5, group=dist.group.WORLD, nens=nens, ens_src=ens_src, schedule="dataflow")
 d.fallback = False                                     # a timeout is a failure here, not a silent half-step run
+if os.environ.get("RX_TEST_INJECT_PEER_STALL"):        # (the stall test: the watchdog path IS the expected one, and quick)
+    d.fallback = True
+    d.verify_peer_steps = 0
+    e.set_sampler_timeout_ms(1500.0)
 from radex_emcee_amd.engine import EngineError
 try:
     st = d.run_mcmc(cfg["walkers"], nsteps)
@@ -340,3 +344,29 @@ def test_two_engines_sample_concurrently_on_one_gpu(co_path, mol):
         assert np.array_equal(chains[k].cpu().numpy(), r.get_chain())
     for e in engs:
         e.close()
+
+
+def test_peer_whose_kernel_never_starts_is_given_up_on_and_the_run_repeated(co_path, mol, tmp_path):
+    """Rank 1's kernel never starts (injected: RX_TEST_INJECT_PEER_STALL).  Rank 0's tasks wait for results that never come; the
+    no-progress watchdog is not armed (not every rank's grid is running: that could be a slow code-object load), so the flat
+    bound of a single wait -- 1.5 s here -- ends the run: abort word in every replica, both ranks see RX_E_TIMEOUT, both repeat
+    the call under the half-step schedule, and the chain is the chain."""
+    from radex_emcee_amd.sampler import DeviceEnsembleSampler
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "peer_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RX_TEST_INJECT_PEER_STALL="1")
+    procs = [subprocess.Popen([sys.executable, "-W", "ignore", str(script), ROOT, str(r), "2", str(port), str(tmp_path), "config2",
+                               "256", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    e = Engine(co_path)
+    p0, ncomp = _setup(e, mol, "config2", 256)
+    ref = DeviceEnsembleSampler(256, 4, engine=e, seed=5)
+    st = ref.run_mcmc(p0, 4)
+    st = ref.run_mcmc(st, 3)
+    for r in range(2):
+        z = np.load(tmp_path / ("peer_%d.npz" % r))
+        assert str(z["schedule"]) == "halfsteps" and "abandoned" in str(z["reason"]), (str(z["schedule"]), str(z["reason"]))
+        assert np.array_equal(z["coords"], st.coords) and np.array_equal(z["chain"], ref.get_chain())
+    e.close()
