@@ -316,6 +316,7 @@ def main():
     kms = eng.time_lnprob_torch(P, lnp[:nmine], st, nit, reps=kreps, stream=stream) if nmine else 0.0
     nitc = nit[:nmine].cpu().numpy()
     stc = st[:nmine].cpu().numpy()
+    nit_blk, st_blk = nitc, stc                    # this rank's block: the launch `kms` was measured on
     if use_dist and world > 1:                     # the statistics of the whole batch, not of rank 0's block
         allst = [None] * world
         dist.all_gather_object(allst, (stc, nitc))
@@ -367,8 +368,8 @@ def main():
         value = evals / dt
         niter_mean = float(nitc[stc != 3].mean()) if solved else 0.0
         algo_bytes = ALGO_BYTES_PER_EVAL * max(nmine, 1)
-        fl = flops_per_eval(float(nit[:nmine].cpu().numpy()[st[:nmine].cpu().numpy() != 3].mean()) if nmine else 0.0) * int(
-            (st[:nmine].cpu().numpy() != 3).sum())                       # of the launch the kernel time belongs to (rank 0's block)
+        solved_blk = int((st_blk != 3).sum())                              # of the launch the kernel time belongs to (rank 0's block)
+        fl = flops_per_eval(float(nit_blk[st_blk != 3].mean()) if solved_blk else 0.0) * solved_blk
         out = {
             "metric": "walker-lnlike evals/sec (1024 walkers, CO 1-comp)" if world == 1 else
                       "walker-lnlike evals/sec (1024 walkers, CO 1-comp) at 1/2/4/8 MI355X",
