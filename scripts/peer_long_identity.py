@@ -42,7 +42,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
     e = Engine(device=0)
     for shape, nw in (("config2", 1024), ("config3", 256)):
         p0, nens, ens_src = setup(e, shape, nw)
-        d = DeviceEnsembleSampler(nw, 4, engine=e, seed=17, group=dist.group.WORLD, nens=nens, ens_src=ens_src)
+        d = DeviceEnsembleSampler(nw, 4, engine=e, seed=17, group=dist.group.WORLD, nens=nens, ens_src=ens_src, schedule="dataflow")
         d.fallback = False
         hx, dt = run(d, p0, nsteps, chunk)
         print("rank %d %s: %s  %s  %.2f s (%.0f walker-steps/s)" % (rank, shape, d.last_schedule, hx, dt, nens * nw * nsteps / dt), flush=True)
