@@ -588,6 +588,21 @@ class DeviceEnsembleSampler:
               os.environ.get("CUDA_VISIBLE_DEVICES"), eng.device)
         infos = self._gather_objects((handle, err, me))
         bad = [i for i, (_, e, _) in enumerate(infos) if e]
+        if not bad and err is None:
+            # A kernel that stores into memory of a GPU it has no peer access to FAULTS (and takes the process down): where this
+            # rank can name the peers' devices -- same host, same *_VISIBLE_DEVICES, so that ordinals mean the same thing --
+            # hipDeviceCanAccessPeer must say yes for every one of them, or the peer-write path is not taken at all
+            from .engine import peer_topology
+            for r, (_, _, m) in enumerate(infos):
+                if r != self.rank and m[:4] == me[:4] and m[4] != me[4]:
+                    t = peer_topology(me[4], m[4])
+                    if t is None or t[0] != 1:
+                        err = "no peer access from device %d to device %d (rank %d)" % (me[4], m[4], r)
+                        break
+            errs = self._gather_objects(err)
+            bad = [i for i, e in enumerate(errs) if e]
+            if bad:
+                infos = [(h, errs[i], m) for i, (h, _, m) in enumerate(infos)]
         if not bad:
             # ranks that share one GPU (rehearsals on a one-GPU box) must all be resident at once: split the CUs
             # (the library counts the replicas that live on its own device itself -- rx_sampler_peer_same_device -- and
