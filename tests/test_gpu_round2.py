@@ -142,7 +142,7 @@ def test_full_width_parity_config5(eng, mol):
     assert np.array_equal(fin, np.isfinite(lnp))
     dok, dmx = _report("config 5, 65536 walkers", lnp, rl, rst)
     assert dok < 1e-4
-    # maxiter tier (observed over 262 144 walkers: worst 1.5e-4, 99.9th percentile 9.5e-7; profiles/r3_big_parity_262144.txt)
+    # maxiter tier (observed over 262 144 walkers: worst 1.5e-4, 99.9th percentile 9.5e-7; profiles/r4_big_parity_262144.txt)
     assert np.percentile(dmx, 99.9) <= 1e-4 and dmx.max() < 1e-3
     # the fluxes themselves, at the same width (north_star's bar is stated on flux).  Two tiers, as README states
     # them: walkers that converge -- 1e-4 relative (+ the background floor) on every line; walkers that stop at
