@@ -68,3 +68,19 @@ def test_no_vector_op_in_front_of_an_exec_restore(asm_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert "0 finding(s)" in last and not last.startswith("0 functions"), last
+
+
+def test_slowpath_build_passes_the_checkers(tmp_path):
+    """The test build that forces every elimination step through the out-of-line pivot path (`make slowpath`, loaded by
+    tests/test_gpu_slowpath.py on the GPU) is different code with different register pressure: the same checks on its CO and toy
+    instantiations (the ones that test runs)."""
+    src = os.path.join(ROOT, "radex_emcee_amd", "csrc", "rx_api.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+           "-mllvm", "-pragma-unroll-threshold=4000000", "-mllvm", "-disable-machine-licm", "-DRX_FORCE_SETTLE",
+           "-DRX_NO_SAMPLER_KERNEL", "-DRX_NL_LIST=8,41", "-DRX_NL_CASES=RX_CASE(8) RX_CASE(41)", "-save-temps", "-c",
+           "-o", "/dev/null", src]
+    subprocess.run(cmd, cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    asm = str(tmp_path / "rx_api-hip-amdgcn-amd-amdhsa-gfx950.s")
+    for script, ok in (("check_spill_exec.py", "0 finding(s)"), ("check_dpp_hazards.py", "0 hazard(s)")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), asm], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and ok in r.stdout.strip().splitlines()[-1], r.stdout[-2000:]
