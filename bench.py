@@ -423,13 +423,18 @@ def main():
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             return float(tm.item())
 
+        import hashlib
+
+        def state_sha1(st_):
+            return hashlib.sha1(np.ascontiguousarray(st_.coords).tobytes() + np.ascontiguousarray(st_.log_prob).tobytes()).hexdigest()[:16]
+
         def timed_run(smp, walkers, nst):
             state = smp.run_mcmc(walkers, 1, store=False)                   # initial log-probabilities + 1 step
             barrier()
             ts = time.perf_counter()
-            smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
+            fin = smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
             barrier()
-            return time.perf_counter() - ts
+            return time.perf_counter() - ts, state_sha1(fin)
 
         for name, ndim, nwk, nst in (("config2", 4, 1024, 60), ("config4", 8, 2048, 12), ("config5", 4, 65536, 6)):
             if name == "config2" and world == 1:
@@ -468,10 +473,11 @@ def main():
                     torch.cuda.synchronize()
                     eng.sampler_stats(True)
                     ts = time.perf_counter()
-                    smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
+                    fin1 = smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
                     torch.cuda.synchronize()
                     d1 = time.perf_counter() - ts
                     st1 = eng.sampler_stats(False)
+                    sha1_one = state_sha1(fin1)
                     del smp
                 d1 = max_over_ranks(d1)
                 rec["one_gpu_dataflow"] = entry(d1, "dataflow: one persistent kernel on ONE GPU (rank 0 alone)", "none",
@@ -481,7 +487,8 @@ def main():
                     # (2) the same ensemble across the ranks, dataflow with peer writes: opt-in, and the sampler compares its first
                     # steps with the half-step schedule on every rank before it relies on the path (falls back by itself)
                     smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp, schedule="dataflow")
-                    d2 = max_over_ranks(timed_run(smp, c["walkers"], nst))
+                    d2, sha2 = timed_run(smp, c["walkers"], nst)
+                    d2 = max_over_ranks(d2)
                     used = smp.last_schedule
                     pre["schedules"][name] = {"requested": "dataflow-peer", "ran": used, "why": smp.schedule_reason,
                                               "peer_verified_against_halfsteps": smp.peer_verified,
@@ -498,14 +505,20 @@ def main():
                     rec["multi_gpu_dataflow"]["ranks_share_one_gpu"] = bool(share)
                     rec["multi_gpu_dataflow"]["schedule_actually_run"] = used
                     rec["multi_gpu_dataflow"]["why"] = smp.schedule_reason
+                    if rank == 0:                        # the same seed, the same start: the final state must be the one-GPU run's, bit for bit
+                        rec["multi_gpu_dataflow"]["same_final_state_as_one_gpu"] = bool(sha2 == sha1_one)
+                        rec["one_gpu_dataflow"]["final_state_sha1"] = sha1_one
                     del smp
                     # (3) north_star's literal form: block evaluation per rank + ONE all_gather of log-probabilities per half-step
                     smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp, schedule="halfsteps")
-                    d3 = max_over_ranks(timed_run(smp, c["walkers"], nst))
+                    d3, sha3 = timed_run(smp, c["walkers"], nst)
+                    d3 = max_over_ranks(d3)
                     rec["multi_gpu_halfsteps_allgather"] = entry(
                         d3, "half-steps: propose, block evaluation per rank, all-gather, accept",
                         "all_gather_into_tensor of %d f64 per half-step (%s)"
                         % (nwk // 2, "gloo rehearsal, host copies" if share else "RCCL, device"), d1)
+                    if rank == 0:
+                        rec["multi_gpu_halfsteps_allgather"]["same_final_state_as_one_gpu"] = bool(sha3 == sha1_one)
                     del smp
                     best = rec["multi_gpu_dataflow"] if d2 <= d3 else rec["multi_gpu_halfsteps_allgather"]
                 else:

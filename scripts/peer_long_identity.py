@@ -1,8 +1,10 @@
-"""Long runs of the peer-write dataflow schedule (two ranks = two processes sharing GPU 0, replicas mapped through
-IPC handles) against the one-GPU dataflow kernel, compared bit for bit: 1024 config-2 prior-box walkers over
+"""Long runs of the peer-write dataflow schedule (one process per rank, replicas mapped through IPC handles) against the
+one-GPU dataflow kernel, compared bit for bit.  On a box with ONE GPU the ranks share it (the rehearsal every record in
+profiles/ comes from); on a node with more, rank r takes GPU r -- THE run that is still missing: stores, atomics and
+release/acquire across xGMI (`python3 scripts/peer_long_identity.py 1200 400 <nranks>`; equal hashes = verified). 1024 config-2 prior-box walkers over
 `nsteps` steps in calls of `chunk` (the ring of versions and its per-step counters turn over 100 times per call),
 then 3 ensembles x 256 walkers with per-ensemble sources.
-usage: python3 scripts/peer_long_identity.py [nsteps=1200] [chunk=400]"""
+usage: python3 scripts/peer_long_identity.py [nsteps=1200] [chunk=400] [nranks=2]"""
 import hashlib, os, socket, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -34,26 +36,33 @@ def run(d, p0, nsteps, chunk):
     return h.hexdigest(), time.perf_counter() - t0
 
 if len(sys.argv) > 1 and sys.argv[1] == "worker":
-    rank, port, nsteps, chunk = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    rank, port, nsteps, chunk, world = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=2)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     from radex_emcee_amd.engine import Engine
     from radex_emcee_amd.sampler import DeviceEnsembleSampler
-    e = Engine(device=0)
+    ndev = torch.cuda.device_count()
+    dev = rank if ndev >= world else 0                    # one GPU per rank where there are enough, else all on GPU 0
+    torch.cuda.set_device(dev)
+    e = Engine(device=dev)
     for shape, nw in (("config2", 1024), ("config3", 256)):
         p0, nens, ens_src = setup(e, shape, nw)
         d = DeviceEnsembleSampler(nw, 4, engine=e, seed=17, group=dist.group.WORLD, nens=nens, ens_src=ens_src, schedule="dataflow")
         d.fallback = False
         hx, dt = run(d, p0, nsteps, chunk)
-        print("rank %d %s: %s  %s  %.2f s (%.0f walker-steps/s)" % (rank, shape, d.last_schedule, hx, dt, nens * nw * nsteps / dt), flush=True)
+        print("rank %d (GPU %d) %s: %s  %s  %.2f s (%.0f walker-steps/s)  verified against half-steps: %s"
+              % (rank, dev, shape, d.last_schedule, hx, dt, nens * nw * nsteps / dt, d.peer_verified), flush=True)
     dist.barrier(); dist.destroy_process_group(); e.close()
     sys.exit(0)
 
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+world = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker", str(r), str(port), str(nsteps), str(chunk)], env=env) for r in range(2)]
+ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker", str(r), str(port), str(nsteps), str(chunk), str(world)], env=env)
+      for r in range(world)]
 rc = [p.wait(timeout=1100) for p in ps]
 from radex_emcee_amd.engine import Engine
 from radex_emcee_amd.sampler import DeviceEnsembleSampler

@@ -114,4 +114,6 @@ def test_bench_gpus_2_starts_its_own_ranks_on_a_shared_gpu():
         assert m["schedule"].startswith("dataflow-peer"), m["schedule"]
         assert m["ranks_share_one_gpu"] is True and m["speedup_vs_1gpu_dataflow"] > 0 and m["speedup_vs_1gpu"] > 0
         assert m["schedule_actually_run"] == "dataflow-peer"
+        # the same seed and start under all three schedules: the final states are the one-GPU run's, bit for bit
+        assert m["same_final_state_as_one_gpu"] is True and sh["multi_gpu_halfsteps_allgather"]["same_final_state_as_one_gpu"] is True
         assert sh["multi_gpu_halfsteps_allgather"]["speedup_vs_1gpu"] > 0
