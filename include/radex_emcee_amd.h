@@ -345,7 +345,10 @@ int rx_time_lnprob_device(rx_handle *h, int N, int ncomp, const double *d_params
                           int32_t *d_status, int32_t *d_niter, void *stream,
                           int reps, double *ms_mean_out);
 
-/* Name of the dominant kernel symbol for the loaded molecule (profiles/).   */
+/* Name of the dominant kernel symbol for the loaded molecule (profiles/):
+ * "rx_solve_kernel<NL, 1, true>" when the molecule takes the specialised
+ * instantiation (it fills the size NL, and its lines are a ladder: line l
+ * connects level l+1 to level l, in file order), "..., false>" otherwise.  */
 const char *rx_kernel_name(const rx_handle *h);
 
 #ifdef __cplusplus

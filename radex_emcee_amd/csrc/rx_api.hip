@@ -257,10 +257,20 @@ int hip_fail(rx_handle *h, hipError_t e, const char *what)
 
 typedef void (*kernel_fn)(const RxKArgs);
 
-// the specialised instantiation: the molecule fills it (no padding levels) AND the geometry is LVG, the hot path
-// (emcee/emcee_radex.py:116 escapeProbGeom='lvg'): no geometry branches in its iteration; sphere / slab run the
-// general instantiation of the same size
-static bool is_exact(const rx_handle *h) { return h->mol.nlev == h->NL && h->method == 2; }
+// the specialised instantiation: the molecule fills it (no padding levels), the geometry is LVG, the hot path
+// (emcee/emcee_radex.py:116 escapeProbGeom='lvg': no geometry branches in its iteration), AND the molecule is a LADDER
+// -- line l connects level l+1 to level l, as in every linear rotor's LAMDA file (CO) -- so that a line and its lower
+// level share a lane and the upper level is the next lane: the per-line / per-level exchanges of the iteration are DPP lane
+// shifts instead of trips through LDS (solve_wave, "ladder").  Everything else runs the general instantiation of the same size.
+static bool is_ladder(const Molecule &m)
+{
+    if (m.nline != m.nlev - 1) return false;
+    for (int l = 0; l < m.nline; ++l)
+        if (m.iupp[l] - 1 != l + 1 || m.ilow[l] - 1 != l) return false;
+    return true;
+}
+// (instantiated for the 41 levels of CO only: kernel_for / sampler_kernel_for)
+static bool is_exact(const rx_handle *h) { return h->NL == 41 && h->mol.nlev == h->NL && h->method == 2 && is_ladder(h->mol); }
 typedef void (*lukernel_fn)(const double *, double *, int32_t *, int, int);
 
 lukernel_fn lukernel_for(int NL)
@@ -588,7 +598,7 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
         h->blocks_per_cu2 = std::min(nb, 2);
     char nm[64];
-    snprintf(nm, sizeof nm, "rx_solve_kernel<%d, 1>", h->NL);
+    snprintf(nm, sizeof nm, "rx_solve_kernel<%d, 1, %s>", h->NL, is_exact(h) ? "true" : "false");
     h->kname = nm;
     return h;
 }

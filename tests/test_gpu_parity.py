@@ -490,10 +490,12 @@ def test_device_pointer_api_on_side_stream(engines, mol):
     assert 0.0 < ms < 1000.0
 
 
-@pytest.mark.parametrize("nlev", [5, 12, 20, 27, 33, 45, 64])
+@pytest.mark.parametrize("nlev", [5, 8, 12, 20, 27, 32, 33, 45, 48, 64])
 def test_every_kernel_instantiation(nlev, tmp_path):
-    """Synthetic rotor ladders of different sizes exercise each padded instantiation
-    (NL = 8, 20, 32, 41, 48, 64), with and without padding levels, against the oracle."""
+    """Synthetic rotor ladders of different sizes exercise each general instantiation (NL = 8, 20, 32, 48, 64), with padding
+    levels (5, 12, 27, 33, 45) and filled exactly (8, 20, 32, 48, 64), against the oracle.  (The specialised ladder form exists
+    for the 41 levels of CO only and is what every other test runs; the general 41-level form runs in
+    test_line_order_that_is_not_a_ladder_... and in the sphere / slab tests.)"""
     from radex_emcee_amd.molecule import synth_co_text
     path = tmp_path / ("rotor%d.dat" % nlev)
     path.write_text(synth_co_text(nlev=nlev))
@@ -519,6 +521,48 @@ def test_every_kernel_instantiation(nlev, tmp_path):
     fin = np.isfinite(rl) & same
     assert np.array_equal(np.isfinite(rl), np.isfinite(lnp))
     assert np.max(np.abs(lnp[fin] - rl[fin]) / np.maximum(np.abs(rl[fin]), 1.0)) < 1e-6
+
+
+def test_line_order_that_is_not_a_ladder_runs_the_general_form(tmp_path):
+    """The ladder form of the 41-level instantiation assumes line l = (level l+1 -> level l) in FILE order (a line and its
+    lower level share a lane).  The same molecule with two lines listed the other way round must not take it: it runs the general
+    instantiation (incidence lists through LDS), and matches the oracle on THAT file -- the accumulation order of matrix_ follows
+    the line order, so the sums differ in the last bits from the ladder file's, and `niter` of a walker on a threshold may too."""
+    from radex_emcee_amd.molecule import synth_co_text
+    lines = synth_co_text(nlev=41).split("\n")
+    i0 = next(k for k, l in enumerate(lines) if l.startswith("!TRANS + UP + LOW + EINSTEINA")) + 1
+    a, b = lines[i0 + 6].split(), lines[i0 + 7].split()
+    a[0], b[0] = b[0], a[0]                                   # (the running index stays 1..40)
+    lines[i0 + 6], lines[i0 + 7] = " ".join(b), " ".join(a)
+    path = tmp_path / "co_swapped.dat"
+    path.write_text("\n".join(lines))
+    eng = Engine(str(path))
+    mol = O.Molecule(str(path))
+    assert eng.nlev == 41 and eng.nline == 40 and eng.kernel_name == "rx_solve_kernel<41, 1, false>"
+    cfg = workloads.config2(256, seed=4242)
+    eng.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), 0.2 * np.ones(10), cfg["bounds"])
+    src = O.Source(cfg["tbg"], cfg["Jup"], np.ones(10), 0.2 * np.ones(10), cfg["bounds"])
+    P = cfg["walkers"]
+    flux, st, nit = eng.model_flux_batch(P, return_info=True)
+    rf, rst, rnit = O.model_flux_batch(mol, src, P)
+    assert np.array_equal(st, rst) and (nit == rnit).mean() >= 0.98
+    same = nit == rnit
+    ok, d = _flux_ok(flux[same], rf[same], P[same], cfg["tbg"], mol)
+    assert ok.all(), d[~ok][:4]
+    # and the two files are the same physics: against the ladder file's engine the fluxes agree to rounding
+    eng0 = Engine()
+    assert eng0.kernel_name == "rx_solve_kernel<41, 1, true>"
+    eng0.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), 0.2 * np.ones(10), cfg["bounds"])
+    f0, st0, nit0 = eng0.model_flux_batch(P, return_info=True)
+    both = (nit == nit0) & (st == 0) & (st0 == 0)
+    assert both.mean() > 0.9
+    # (model_lvg picks result[Jup - 1] by POSITION in the file, emcee/emcee_radex.py:129: the swapped file's columns for
+    # Jup = 7 and 8 are each other's lines)
+    col = list(cfg["Jup"])
+    k7, k8 = col.index(7), col.index(8)
+    f0[:, [k7, k8]] = f0[:, [k8, k7]]
+    assert np.nanmax(np.abs(flux[both] - f0[both]) / np.maximum(np.abs(f0[both]), 1e-300)) < 1e-6
+    eng.close(); eng0.close()
 
 
 def test_batch_shapes_and_limits(engines, mol):
