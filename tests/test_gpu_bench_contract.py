@@ -103,7 +103,8 @@ def test_bench_gpus_2_starts_its_own_ranks_on_a_shared_gpu():
     assert pre["peer_access"][0][0]["can_access_peer"] == 1
     for name in ("config2", "config4", "config5"):
         sc = pre["schedules"][name]
-        assert sc["ran"] == "dataflow-peer" and sc["peer_verified_against_halfsteps"] is True, json.dumps(sc)   # (the whole record: "why")
+        assert sc["ran"] == "dataflow-peer" and sc["peer_verified_against_halfsteps"] is True, \
+            json.dumps(sc) + "\n" + out.stderr[-1500:]                  # (the whole record -- "why" -- and the ranks' warnings)
         assert "identical" in sc["why"] and sc["replicas_on_this_device"] == 2
     c2 = d["sharded"]["config2"]                       # BASELINE configs[1] as ONE ensemble in the sampler, strong scaled
     assert c2["walkers"] == 1024 and c2["proposals_per_rank"] == 256
