@@ -246,8 +246,9 @@ int rx_set_sampler_grid_limit(rx_handle *h, int cus);
  *   rx_set_sampler_stall_ms  no-progress watchdog of every wait inside the dataflow kernels (default 100 ms): a waiting task
  *                            gives up -- abort word, all grids drain, RX_E_TIMEOUT from rx_sampler_wait / _peer_finish -- when
  *                            no task of ANY rank has finished for that long while every rank's grid is running (a rank that is
- *                            still loading its code object does not count as a stall).  A task lasts a few milliseconds at
- *                            most.  rx_set_sampler_timeout_ms (default now 10 s) stays the flat bound of a single wait.
+ *                            still loading its code object does not count as a stall) and the launch's FIRST task has finished
+ *                            (what happens once -- the first access through a peer mapping -- is not a stall either; the
+ *                            mappings are also touched by rx_sampler_peer_connect).  A task lasts a few milliseconds at most.  rx_set_sampler_timeout_ms (default now 10 s) stays the flat bound of a single wait.
  *   rx_sampler_peer_abort    raises the abort word in every connected replica from the HOST (a stream of its own): the rank
  *                            whose launch failed ends the others' kernels at once instead of letting them run into the watchdog. */
 int rx_sampler_peer_same_device(const rx_handle *h);

@@ -1246,6 +1246,11 @@ int rx_sampler_peer_connect(rx_handle *h, const void *ipc_handles, void *const *
     }
     if (!P.d_bases) HIPCHK(h, hipMalloc(&P.d_bases, RX_MAX_RANKS * sizeof(char *)));
     HIPCHK(h, hipMemcpy(P.d_bases, P.base, RX_MAX_RANKS * sizeof(char *), hipMemcpyHostToDevice));
+    // The mappings were opened with hipIpcMemLazyEnablePeerAccess: whatever the first access from this device sets up is set
+    // up HERE, by reading one word of every peer's block (a read: harmless whatever the peer is doing), not inside the first
+    // launch under the no-progress watchdog
+    for (int r = 0; r < P.nranks; ++r)
+        if (r != P.rank) HIPCHK(h, hipMemcpy(h->d_queue, P.base[r] + P.off_abort, sizeof(uint32_t), hipMemcpyDeviceToDevice));
     P.connected = true;
     return 0;
 }
