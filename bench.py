@@ -384,7 +384,7 @@ def main():
                        "molecule": os.path.basename(eng.molfile), "walkers": nw, "walkers_per_gpu": per,
                        "kernel": eng.kernel_name, "niter_mean": round(niter_mean, 2),
                        "niter_max": int(nitc.max()), "maxiter_walkers": int((stc == 1).sum()),
-                       "collective": None if world == 1 else "all_gather_into_tensor(%d x f64) per step, %s"
+                       "collective": None if not use_dist else "all_gather_into_tensor(%d x f64) per step, %s"
                                      % (per * world, "gloo rehearsal on one GPU" if share else "nccl (RCCL)")},
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (kms * 1e-3) / 1e9, 6),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",

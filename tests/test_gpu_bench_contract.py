@@ -118,3 +118,28 @@ def test_bench_gpus_2_starts_its_own_ranks_on_a_shared_gpu():
         # the same seed and start under all three schedules: the final states are the one-GPU run's, bit for bit
         assert m["same_final_state_as_one_gpu"] is True and sh["multi_gpu_halfsteps_allgather"]["same_final_state_as_one_gpu"] is True
         assert sh["multi_gpu_halfsteps_allgather"]["speedup_vs_1gpu"] > 0
+
+
+def test_bench_collectives_over_rccl_with_a_one_rank_group():
+    """RX_BENCH_FORCE_DIST=1: the process group is initialised with the nccl (= RCCL) backend and every collective of the N > 1
+    code path runs on DEVICE buffers -- the world-size count, the all_gather_into_tensor inside the timed step, the barriers, the
+    max over ranks -- with ONE rank: what a one-GPU box can exercise of the path the shared-GPU rehearsal runs over gloo."""
+    env = dict(os.environ, RX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-large-batch", "--no-config3"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    pre = d["preflight"]
+    assert pre["backend"] == "nccl" and pre["world_size_counted_by_all_reduce"] == 1 and pre["ranks_share_one_gpu"] is False
+    assert "all_gather_into_tensor" in (d["config"]["collective"] or "")
+    for name in ("config4", "config5"):                  # a group of one rank: the peer form of the kernel on its replica block
+        sc = pre["schedules"][name]
+        assert sc["ran"] == "dataflow-peer", json.dumps(sc)
+        sh = d["sharded"][name]
+        assert sh["multi_gpu_dataflow"]["same_final_state_as_one_gpu"] is True
+        assert sh["multi_gpu_halfsteps_allgather"]["same_final_state_as_one_gpu"] is True
