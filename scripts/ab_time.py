@@ -8,7 +8,8 @@ sys.path.insert(0, ".")
 from radex_emcee_amd.engine import Engine
 from radex_emcee_amd import workloads
 n, reps = int(sys.argv[1]), int(sys.argv[2])
-cfg = workloads.config2(n, seed=5678 if n != 1024 else 1234)
+import os
+cfg = workloads.config2(n, seed=int(os.environ.get("RX_AB_SEED", "5678" if n != 1024 else "1234")))
 e = Engine(); e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
 P = torch.from_numpy(cfg["walkers"]).cuda()
 o = [torch.empty(n, dtype=t, device="cuda") for t in (torch.float64, torch.int32, torch.int32)]
