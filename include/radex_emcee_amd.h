@@ -221,6 +221,12 @@ int rx_set_sampler_timeout_ms(rx_handle *h, double ms);
  *                            first and sum over ranks);  rx_sampler_wait            ... barrier ...
  *   rx_sampler_peer_finish   final state -> d_coords / d_lnp / d_naccept; RX_E_TIMEOUT if a task on ANY rank
  *                            gave up waiting (every rank then reports it)
+ *   rx_sampler_peer_disconnect  unmaps the peers' replicas (hipIpcCloseMemHandle) and keeps this rank's own block;
+ *   rx_sampler_peer_close    ... then frees it too (rx_sampler_peer_setup does this to a previous set-up by itself).  A
+ *                            block must not be freed -- or its successor exported -- while a peer still has it mapped:
+ *                            across processes the order is  disconnect on every rank ... barrier ... close / setup
+ *                            (exporting the next block while a peer still mapped the last one made hipIpcGetMemHandle fail
+ *                            with "invalid argument" now and then, more often with four ranks than with two)
  *   rx_set_sampler_grid_limit  rx_sampler_peer_run occupies at most `cus` compute units (0 = the whole GPU): ranks
  *                            that SHARE one GPU (rehearsals) must all be resident at once                   */
 int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwalkers, int ncomp,
@@ -233,6 +239,7 @@ int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, in
                         const int32_t *d_ens_src, double *d_chain, double *d_chain_lnp, void *stream);
 int rx_sampler_peer_finish(rx_handle *h, double *d_coords, double *d_lnp, int32_t *d_naccept,
                            void *stream);
+int rx_sampler_peer_disconnect(rx_handle *h);
 int rx_sampler_peer_close(rx_handle *h);
 int rx_set_sampler_grid_limit(rx_handle *h, int cus);
 /* Residency and failure handling of the persistent kernels.

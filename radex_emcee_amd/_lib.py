@@ -30,6 +30,7 @@ EXPORTS = [
     "rx_sampler_peer_run", "rx_sampler_peer_finish", "rx_sampler_peer_close", "rx_set_sampler_grid_limit",
     "rx_sampler_stats", "rx_lnprior_batch", "rx_set_sampler_speculation", "rx_sampler_spec_stats",
     "rx_sampler_peer_same_device", "rx_set_sampler_stall_ms", "rx_sampler_peer_abort", "rx_peer_topology",
+    "rx_sampler_peer_disconnect",
 ]
 ABI_VERSION = 4
 RX_MAX_RANKS = 8
@@ -133,6 +134,7 @@ def load():
     L.rx_sampler_peer_run.argtypes = [vp, C.c_double, u64, i64, C.c_int, vp, vp, vp, vp]
     L.rx_sampler_peer_finish.argtypes = [vp, vp, vp, vp, vp]
     L.rx_sampler_peer_close.argtypes = [vp]
+    L.rx_sampler_peer_disconnect.argtypes = [vp]
     L.rx_set_sampler_grid_limit.argtypes = [vp, C.c_int]
     L.rx_sampler_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
     L.rx_sampler_spec_stats.argtypes = [vp, C.POINTER(C.c_uint64)]

@@ -1156,6 +1156,19 @@ int rx_set_sampler_grid_limit(rx_handle *h, int blocks)
     return 0;
 }
 
+int rx_sampler_peer_disconnect(rx_handle *h)
+{
+    if (!h) return RX_E_ARG;
+    rx_handle::Peer &P = h->peer;
+    if (!P.own && !P.d_bases) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->in_flight && h->ev_done) { (void)hipEventSynchronize(h->ev_done); h->in_flight = false; }
+    for (int r = 0; r < RX_MAX_RANKS; ++r)
+        if (P.opened[r] && P.base[r]) { (void)hipIpcCloseMemHandle(P.base[r]); P.opened[r] = false; P.base[r] = nullptr; }
+    P.connected = false; P.begun = false;
+    return 0;
+}
+
 int rx_sampler_peer_close(rx_handle *h)
 {
     if (!h) return RX_E_ARG;

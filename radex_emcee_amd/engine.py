@@ -324,6 +324,10 @@ class Engine:
                                                  0 if naccept is None else naccept.data_ptr(),
                                                  self._stream(coords.device, stream)), "rx_sampler_peer_finish")
 
+    def sampler_peer_disconnect(self):
+        """Unmaps the peers' replicas, keeps this rank's own block (every rank, then a barrier, then close / the next set-up)."""
+        self._chk(self._L.rx_sampler_peer_disconnect(self._h), "rx_sampler_peer_disconnect")
+
     def sampler_peer_close(self):
         self._chk(self._L.rx_sampler_peer_close(self._h), "rx_sampler_peer_close")
 

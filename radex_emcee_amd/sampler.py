@@ -573,6 +573,17 @@ class DeviceEnsembleSampler:
         if self.world > 1:
             self._dist.barrier(group=self.group)
 
+    def _peer_teardown(self):
+        """Collective: every rank unmaps its peers' replicas, THEN (behind a barrier) frees its own block -- a block must not be
+        freed, nor its successor exported, while a peer still has it mapped."""
+        from .engine import EngineError
+        for step in (self.engine.sampler_peer_disconnect, self.engine.sampler_peer_close):
+            try:
+                step()
+            except EngineError:
+                pass
+            self._gather_objects(None)                 # (= barrier, on whatever transport the group has)
+
     def _peer_setup(self):
         """Allocates this rank's replica, exchanges the IPC handles, maps the peers'.  Collective: every rank
         learns whether ALL ranks succeeded; otherwise all fall back to the half-step schedule together."""
@@ -580,6 +591,7 @@ class DeviceEnsembleSampler:
         import socket
         from .engine import EngineError
         eng, err, handle = self.engine, None, None
+        self._peer_teardown()                          # what an earlier sampler left on this handle (collective like the rest)
         try:
             handle = eng.sampler_peer_setup(self.world, self.rank, self.nens, self.nwalkers, self.ndim // 4)
         except EngineError as exc:
@@ -619,10 +631,7 @@ class DeviceEnsembleSampler:
         else:
             err = "rank %d: %s" % (bad[0], infos[bad[0]][1])
         if bad:
-            try:
-                eng.sampler_peer_close()
-            except EngineError:
-                pass
+            self._peer_teardown()
             self.peer_state = err
             if self.rank == 0:
                 import warnings
@@ -783,10 +792,7 @@ class DeviceEnsembleSampler:
                 if self.rank == 0:
                     import warnings
                     warnings.warn("multi-GPU dataflow sampler: %s; half-steps + all_gather instead" % self.peer_state)
-                try:
-                    self.engine.sampler_peer_close()
-                except EngineError:
-                    pass
+                self._peer_teardown()
                 peer = False
                 if chain is not None:
                     chain = torch.empty_like(chain)
