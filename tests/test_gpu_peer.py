@@ -48,7 +48,7 @@ import numpy as np
 sys.path.insert(0, sys.argv[1])
 import torch
 from radex_emcee_amd import workloads
-from radex_emcee_amd.engine import Engine
+from radex_emcee_amd.engine import Engine, EngineError
 from radex_emcee_amd.sampler import DeviceEnsembleSampler
 dev = torch.device("cuda", 0)
 ncu = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -108,6 +108,19 @@ for shape, nw, nsteps in (("config2", 1024, 14), ("config4", 256, 5)):
     # every row of the chain was written by exactly one rank
     w0, w1 = (state[0][4] != 0).cpu().numpy(), (state[1][4] != 0).cpu().numpy()
     assert not (w0 & w1).any() and (w0 | w1).all() and w0.sum() == w1.sum()
+    # teardown in the order the multi-process form needs: every rank unmaps its peers' blocks, THEN the blocks are freed
+    # (and a handle can be set up again afterwards)
+    for e in engs:
+        e.sampler_peer_disconnect()
+    try:
+        engs[0].sampler_peer_begin(*state[0][:3], stream=streams[0].cuda_stream)
+        raise AssertionError("begin after disconnect must be refused")
+    except EngineError:
+        pass
+    for e in engs:
+        e.sampler_peer_close()
+    engs[0].sampler_peer_setup(2, 0, 1, nw, ncomp, export=False)
+    assert engs[0].sampler_peer_base()
     for e in engs:
         e.sampler_peer_close()
         e.close()
