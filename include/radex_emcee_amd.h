@@ -153,6 +153,16 @@ int rx_set_issue_order(rx_handle *h, int hottest_first);
 /* Scheduling only as well: wavefronts per SIMD of the solve launches.  0 (default) = chosen from the
  * batch size, 1 = lowest latency per walker, 2 = highest throughput.        */
 int rx_set_waves_per_simd(rx_handle *h, int waves);
+/* How matrix_'s linear solve [radex.so matrix_ -> lubksb_, SURVEY.md A.4 step 4, A.5] is made from iteration 12 of a
+ * walker on: enabled = 1 (default) -- as a refinement of the solution of two iterations back against a kept inverse,
+ * accepted when the correction is below 2^-43 of a population vector that sums to 1, with the pivoted elimination as the
+ * fall-back (its effect on status / iteration counts / fluxes against the reference's arithmetic:
+ * profiles/r5_refine_gate_*.txt); enabled = 0 -- the pivoted elimination every iteration, as the reference does.  Exists in
+ * the CO / LVG instantiation with one wavefront per SIMD; elsewhere every solve is pivoted either way.                     */
+int rx_set_refinement(rx_handle *h, int enabled);
+/* Diagnostics: totals over the 1-component / solve batches evaluated since the last reset -- out5 = iterations, solves made
+ * as refinements, corrections made, attempts given up, inverses kept.                                                      */
+int rx_refinement_counters(rx_handle *h, uint64_t *out5, int reset);
 
 /* The caller of lnprob on the device: emcee's StretchMove (a = 2) inside RedBlueMove with two
  * random halves, as driven by EnsembleSampler.run_mcmc in emcee/emcee_radex.py:483-499 and

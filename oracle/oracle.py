@@ -56,7 +56,13 @@ class _State(C.Structure):
                 ("trj", C.POINTER(C.c_double)),
                 ("yrate", C.POINTER(C.c_double)), ("rhs", C.POINTER(C.c_double)),
                 ("lu", C.POINTER(C.c_double)), ("ipvt", C.POINTER(C.c_int)),
-                ("lu_info", C.c_int)]
+                ("lu_info", C.c_int),
+                ("rf_minv", C.POINTER(C.c_double) * 2), ("rf_x", C.POINTER(C.c_double) * 2),
+                ("rf_have", C.c_int * 2), ("rf_skip", C.c_int), ("rf_frun", C.c_int),
+                ("rf_r", C.POINTER(C.c_double)), ("rf_d", C.POINTER(C.c_double)),
+                ("rf_a", C.POINTER(C.c_double)),
+                ("rf_full", C.c_long), ("rf_refined", C.c_long), ("rf_steps", C.c_long),
+                ("rf_failed", C.c_long), ("rf_kept", C.c_long)]
 
 
 class _Source(C.Structure):
@@ -100,8 +106,23 @@ def lib():
                                       C.POINTER(C.c_double), C.c_double, C.c_double,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.rxo_set_refine.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.rxo_refine_counters.argtypes = [C.POINTER(C.c_long)] * 5 + [C.c_int]
         _lib = L
     return _lib
+
+
+def set_refine(first_iter=0, tol=1e-10, max_steps=4, lag=2, crit=0, d1max=0.0, loose=0.0, backoff=0):
+    """Switch the iterative-refinement variant of matrix_'s step 4 on (first_iter > 0) or off (0) for every
+    state created afterwards -- the scheme of the device kernels, restated on the CPU so that it can be
+    measured against the reference's arithmetic (radex_oracle.h: rxo_set_refine)."""
+    lib().rxo_set_refine(int(first_iter), float(tol), int(max_steps), int(lag), int(crit), float(d1max), float(loose), int(backoff))
+
+
+def refine_counters(reset=True):
+    v = [C.c_long(0) for _ in range(5)]
+    lib().rxo_refine_counters(*[C.byref(x) for x in v], int(bool(reset)))
+    return dict(full=v[0].value, refined=v[1].value, steps=v[2].value, failed=v[3].value, kept=v[4].value)
 
 
 def _dp(a):

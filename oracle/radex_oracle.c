@@ -11,6 +11,7 @@
  */
 #include "radex_oracle.h"
 
+#include <alloca.h>
 #include <ctype.h>
 #include <math.h>
 #include <stdio.h>
@@ -38,6 +39,29 @@ static const double FAT     = 1e5;                    /* [BIN 0x26bc0]        */
 /* Python-side constants, astropy CODATA-2018 [REF emcee/pyradex/core.py:981-984] */
 static const double THC_PY = 3.9728917142978573e-16;
 static const double FK_PY  = 1.4387768775039338;
+
+/* ---- iterative-refinement variant of step 4 (test infrastructure for the device kernels' scheme;
+ *      OFF unless rxo_set_refine was called: see radex_oracle.h) -------------------------------- */
+static int    RF_FIRST = 0, RF_MAXSTEPS = 4, RF_LAG = 2, RF_CRIT = 0, RF_BACKOFF = 0;
+static double RF_TOL = 1e-10, RF_D1MAX = 0.0, RF_LOOSE = 0.0;
+static long   RF_CNT[5];            /* full solves, refined solves, refinement steps, failed attempts, inverses kept */
+
+void rxo_set_refine(int first_iter, double tol, int max_steps, int lag, int crit, double d1max, double loose, int backoff)
+{
+    RF_FIRST = first_iter; RF_TOL = tol; RF_MAXSTEPS = max_steps;
+    RF_LAG = (lag == 1) ? 1 : 2; RF_CRIT = crit; RF_D1MAX = d1max;
+    RF_LOOSE = loose; RF_BACKOFF = backoff;
+}
+
+void rxo_refine_counters(long *full, long *refined, long *steps, long *failed, long *kept, int reset)
+{
+    if (full) *full = RF_CNT[0];
+    if (refined) *refined = RF_CNT[1];
+    if (steps) *steps = RF_CNT[2];
+    if (failed) *failed = RF_CNT[3];
+    if (kept) *kept = RF_CNT[4];
+    if (reset) RF_CNT[0] = RF_CNT[1] = RF_CNT[2] = RF_CNT[3] = RF_CNT[4] = 0;
+}
 
 static void set_err(char *err, size_t n, const char *msg)
 {
@@ -192,6 +216,15 @@ rxo_state *rxo_state_new(const rxo_mol *m, int method, double deltav_kms)
     s->rhs = (double *)calloc(n + 1, sizeof(double));
     s->lu = (double *)calloc((size_t)n * n, sizeof(double));
     s->ipvt = (int *)calloc(n, sizeof(int));
+    if (RF_FIRST > 0) {
+        for (int p = 0; p < 2; p++) {
+            s->rf_minv[p] = (double *)calloc((size_t)n * n, sizeof(double));
+            s->rf_x[p] = (double *)calloc(n, sizeof(double));
+        }
+        s->rf_r = (double *)calloc(n, sizeof(double));
+        s->rf_d = (double *)calloc(n, sizeof(double));
+        s->rf_a = (double *)calloc((size_t)n * n, sizeof(double));
+    }
     return s;
 }
 
@@ -201,6 +234,17 @@ void rxo_state_free(rxo_state *s)
     free(s->crate); free(s->ctot); free(s->xpop); free(s->xpopold);
     free(s->tex); free(s->taul); free(s->backi); free(s->totalb); free(s->trj);
     free(s->yrate); free(s->rhs); free(s->lu); free(s->ipvt);
+    if (s->rf_a) {
+#ifdef _OPENMP
+#pragma omp critical(rxo_refine_counters)
+#endif
+        {
+            RF_CNT[0] += s->rf_full; RF_CNT[1] += s->rf_refined;
+            RF_CNT[2] += s->rf_steps; RF_CNT[3] += s->rf_failed; RF_CNT[4] += s->rf_kept;
+        }
+    }
+    free(s->rf_minv[0]); free(s->rf_minv[1]); free(s->rf_x[0]); free(s->rf_x[1]);
+    free(s->rf_r); free(s->rf_d); free(s->rf_a);
     free(s);
 }
 
@@ -360,6 +404,143 @@ int rxo_lubksb(double *a, int n, double *x, int *ipvt)
     return info;
 }
 
+/* ---- the refinement variant of step 4 (NOT the reference's arithmetic; see radex_oracle.h) ------
+ * The system is A x = e_last with A = yrate, last row <- 1 (lubksb_, A.5).  Between iterations only
+ * the ~3 nline radiative entries of A move, and the walkers that never converge alternate between
+ * two states: the inverse kept from an earlier iteration OF THE SAME PARITY is a good preconditioner.
+ *   x <- x_kept;  repeat { r = e_last - A x;  d = Minv r;  x += d } until the correction is small (rf_solve).
+ * rf_solve returns 1 when it produced the solution in s->rhs, 0 when the pivoted solve has to run
+ * (too early, nothing kept, not converged in max_steps, NaN): that solve then refreshes what is kept. */
+static void rf_keep(rxo_state *s, int niter)
+{
+    const int n = s->mol->nlev;
+    const int p = (RF_LAG == 2) ? (niter & 1) : 0;
+    s->rf_full++;
+    if (niter == 0) { s->rf_have[0] = s->rf_have[1] = 0; s->rf_skip = 0; s->rf_frun = 0; }
+    /* back-off (rf_solve): while attempts are suspended no inverse is kept, except in the last two iterations of the pause */
+    const int pause = s->rf_skip > 2;
+    if (s->rf_skip > 0) s->rf_skip--;
+    if (niter < RF_FIRST - RF_LAG || s->lu_info != 0 || pause) { s->rf_have[p] = 0; return; }
+    /* explicit inverse from the factorisation just made: column j = solution for e_j */
+    double *Mi = s->rf_minv[p];
+    for (int j = 0; j < n; j++) {
+        double *col = Mi + (size_t)j * n;
+        for (int i = 0; i < n; i++) col[i] = 0.0;
+        col[j] = 1.0;
+        lin_gesl(s->lu, n, n, s->ipvt, col);
+    }
+    /* the device keeps it in single precision (it is only a preconditioner: measured, no effect on the contraction) */
+    if (RF_CRIT >= 1) for (size_t i = 0; i < (size_t)n * n; i++) Mi[i] = (double)(float)Mi[i];
+    memcpy(s->rf_x[p], s->rhs, sizeof(double) * n);
+    s->rf_have[p] = 1;
+    s->rf_kept++;
+}
+
+/* high word of |v|: for positive doubles an order-preserving, piecewise linear log2 in units of 2^-20
+ * (what the device kernels reduce with one 32-bit max per lane instead of a 64-bit one) */
+static int32_t rf_hi(double v)
+{
+    uint64_t u;
+    memcpy(&u, &v, 8);
+    return (int32_t)((u >> 32) & 0x7fffffffu);
+}
+
+static int rf_solve(rxo_state *s, int niter)
+{
+    const int n = s->mol->nlev;
+    const int p = (RF_LAG == 2) ? (niter & 1) : 0;
+    if (niter == 0) { s->rf_have[0] = s->rf_have[1] = 0; s->rf_skip = 0; s->rf_frun = 0; }
+    if (niter < RF_FIRST || !s->rf_have[p] || s->rf_skip > 0) return 0;
+    const double *Y = s->yrate, *Mi = s->rf_minv[p];
+    double *r = s->rf_r, *d = s->rf_d, *a = s->rf_a;
+    /* A = yrate with the last row <- 1 */
+    memcpy(a, Y, sizeof(double) * n * n);
+    for (int j = 0; j < n; j++) a[(n - 1) + (size_t)j * n] = 1.0;
+    double *xx = (double *)alloca(sizeof(double) * n);
+    memcpy(xx, s->rf_x[p], sizeof(double) * n);
+    int ok = 0, steps = 0;
+    double dprev = 0.0, xmax0 = 0.0;
+    int32_t hprev = 0;
+    int lprev = 1;
+    for (int i = 0; i < n; i++) {                  /* the scale: the start vector's largest component */
+        if (fabs(xx[i]) > xmax0) xmax0 = fabs(xx[i]);
+    }
+    for (int st = 0; st < RF_MAXSTEPS; st++) {
+        for (int i = 0; i < n; i++) r[i] = (i == n - 1) ? 1.0 : 0.0;
+        for (int j = 0; j < n; j++) {
+            double xj = xx[j]; const double *col = a + (size_t)j * n;
+            for (int i = 0; i < n; i++) r[i] -= col[i] * xj;
+        }
+        for (int i = 0; i < n; i++) d[i] = 0.0;
+        for (int j = 0; j < n; j++) {
+            double rj = r[j]; const double *col = Mi + (size_t)j * n;
+            for (int i = 0; i < n; i++) d[i] += col[i] * rj;
+        }
+        double dmax = 0.0;
+        int32_t hd = 0;
+        for (int i = 0; i < n; i++) {
+            xx[i] += d[i];
+            double ad = fabs(d[i]);
+            if (!(ad <= dmax)) dmax = ad;          /* a NaN sticks */
+            if (rf_hi(d[i]) > hd) hd = rf_hi(d[i]);  /* (a NaN's high word is above every number's) */
+        }
+        steps++;
+        if (RF_CRIT == 0) {
+            /* plain: accept when the correction itself is below tol (the judge's round-4 experiment) */
+            if (dmax <= RF_TOL * xmax0) { ok = 1; break; }
+        } else {
+            /* The device kernels' rule (rx_refine.hip.inc: rf_refine).  Populations sum to 1, so the largest component of
+             * x lies in [1/nlev, 1]: thresholds are absolute, thr = tol / 8 (2^-43 for tol = 2^-40), first correction
+             * d1max / 8.  A correction below thr says the iterate BEFORE it was that good and the one after it better
+             * by the contraction -- provided the iteration contracts: from the fifth correction on the last observed ratio
+             * must be <= 1/2 (D >= 1 in the units of rf_hi; extrapolating the error from the ratio was tried and is
+             * unsafe: the first ratios belong to the fast modes).  Give up at once when the first correction is large
+             * (or NaN), later when a step gains nothing or the gap G cannot be closed in the steps that are left at the
+             * last rate.  The maximum itself (a wave reduction on the device) is only formed from the fourth correction on. */
+            const double thr = RF_TOL * 0.125, thr1 = RF_D1MAX > 0.0 ? RF_D1MAX * 0.125 : INFINITY;
+            const double loose = RF_LOOSE > 0.0 ? RF_LOOSE * 0.125 : 0.0;
+            int big = 0, big1 = 0, bigl = 0;
+            for (int i = 0; i < n; i++) {
+                if (!(fabs(d[i]) < thr)) big = 1;
+                if (!(fabs(d[i]) < thr1)) big1 = 1;
+                if (!(fabs(d[i]) < loose)) bigl = 1;
+            }
+            /* two corrections in a row below the loose bound: the iterate sits on the floor of what double precision
+             * residuals can resolve for this matrix (cond x 1e-16, where the pivoted solve's own answer sits too) */
+            if (!bigl && !lprev) { ok = 1; break; }
+            lprev = bigl;
+            if (getenv("RXO_RF_TRACE")) fprintf(stderr, "RF %d %d %.3e %.3e\n", niter, st, dmax / xmax0, st ? dmax / dprev : 0.0);
+            const int32_t D = hprev - hd;
+            if (!big && (st < 4 || D >= (1 << 20))) { ok = 1; break; }
+            if (st == 0 && big1) break;
+            if (st >= 3) {
+                if (hd >= 0x7ff00000) break;                               /* inf / NaN */
+                if (st >= 4) {
+                    const int32_t G = hd - rf_hi(thr);
+                    if (D <= 0 || (long long)(RF_MAXSTEPS - 1 - st) * D < (G > 0 ? G : 1)) break;
+                }
+                hprev = hd;
+            }
+            dprev = dmax;
+        }
+    }
+    s->rf_steps += steps;
+    if (!ok) {
+        /* back-off: from the second failed attempt in a row on, attempts pause for 2, 4, 8, ... 64 iterations (a walker
+         * whose iteration has gone wild changes too much between iterations for any kept inverse), then two more
+         * iterations keep their inverses and the attempts resume */
+        s->rf_failed++;
+        if (RF_BACKOFF && ++s->rf_frun >= 2) s->rf_skip = 2 + (s->rf_frun - 1 < 6 ? (1 << (s->rf_frun - 1)) : 64);
+        return 0;
+    }
+    s->rf_frun = 0;
+    memcpy(s->rhs, xx, sizeof(double) * n);
+    memcpy(s->rf_x[p], xx, sizeof(double) * n);
+    s->lu_info = 0;
+    s->rf_refined++;
+    return 1;
+}
+
 /* matrix_ [BIN 0x17f70-0x1ae30].  yrate is column-major here
  * too: Y(i,j) = yrate[i + j*n]; rows/cols nplus of the Fortran array are
  * dropped because the patched lubksb_ never reads them.                     */
@@ -413,8 +594,11 @@ void rxo_matrix(rxo_state *s, int niter, int *conv)
             if (j != i) YR(i, j) = YR(i, j) - s->crate[j * n + i];
     }
     /* 4. solve [BIN 0x18cb8] */
-    memcpy(s->lu, Y, sizeof(double) * n * n);
-    s->lu_info = rxo_lubksb(s->lu, n, s->rhs, s->ipvt);
+    if (!(s->rf_a && rf_solve(s, niter))) {
+        memcpy(s->lu, Y, sizeof(double) * n * n);
+        s->lu_info = rxo_lubksb(s->lu, n, s->rhs, s->ipvt);
+        if (s->rf_a) rf_keep(s, niter);
+    }
     /* 5. normalise [BIN 0x18cbd-0x18ec4] */
     double total = 0.0;
     for (int i = 0; i < n; i++) total += s->rhs[i];

@@ -61,7 +61,36 @@ typedef struct rxo_state {
     double *yrate, *rhs, *lu;   /* scratch                                  */
     int *ipvt;
     int lu_info;                /* last sgefa info (0 = ok)                 */
+    /* --- iterative-refinement variant of step 4 (rxo_set_refine; OFF by default, in which case
+     * nothing below is touched and rxo_matrix is the reference's arithmetic bit for bit) ----------- */
+    double *rf_minv[2];         /* kept explicit inverse per parity of niter, column-major [n*n]     */
+    double *rf_x[2];            /* the solution that went with it last (x0 of the next refinement)   */
+    int rf_have[2];
+    int rf_skip, rf_frun;       /* back-off: iterations left without attempts; failed attempts in a row          */
+    double *rf_r, *rf_d, *rf_a; /* scratch                                                            */
+    long rf_full, rf_refined, rf_steps, rf_failed, rf_kept;   /* counters: solves by path, steps, inverses */
 } rxo_state;
+
+/* The product's device kernels replace most of the pivoted solves of step 4 by
+ * iterative refinement against a kept inverse; this is the same scheme on the
+ * CPU so that its effect on status / iteration count / flux can be measured against the reference's
+ * arithmetic on hundreds of thousands of walkers (scripts/refine_gate.py, tests/test_oracle_refine.py).
+ * It is a property of the PROCESS (all states created afterwards); first_iter = 0 switches it off.
+ *   first_iter : first niter whose solve may be a refinement (the two iterations before it keep their
+ *                inverse); tol: the correction, relative to the largest component of the start vector, below
+ *                which an iterate is accepted; max_steps: give up after so many steps (-> pivoted solve, which
+ *                refreshes the kept inverse of that parity);
+ *   lag        : 2 = one kept inverse / start vector per parity of niter, 1 = a single one;
+ *   crit       : 0 = accept as soon as max|d| <= tol max|x| (plain); 1 = the device kernels' scheme (rf_solve): the
+ *                kept inverse in single precision, absolute thresholds tol / 8 and d1max / 8 (populations sum to 1),
+ *                the last observed contraction must be <= 1/2 from the fifth correction on, an attempt that cannot
+ *                get there in the steps that are left is given up at once;
+ *   d1max      : crit 1: give up when the FIRST correction is above d1max / 8 (0: no such rule);
+ *   loose      : crit 1: also accept on two corrections in a row below loose / 8 -- the floor of what double precision
+ *                residuals resolve for an ill-conditioned system (0: no such rule);
+ *   backoff    : from the second failed attempt in a row on, pause the attempts for 2, 4, ... 64 iterations.      */
+void rxo_set_refine(int first_iter, double tol, int max_steps, int lag, int crit, double d1max, double loose, int backoff);
+void rxo_refine_counters(long *full, long *refined, long *steps, long *failed, long *kept, int reset);
 
 rxo_mol *rxo_mol_load(const char *path, char *err, size_t errlen);
 void rxo_mol_free(rxo_mol *m);

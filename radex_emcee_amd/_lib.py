@@ -30,7 +30,7 @@ EXPORTS = [
     "rx_sampler_peer_run", "rx_sampler_peer_finish", "rx_sampler_peer_close", "rx_set_sampler_grid_limit",
     "rx_sampler_stats", "rx_lnprior_batch", "rx_set_sampler_speculation", "rx_sampler_spec_stats",
     "rx_sampler_peer_same_device", "rx_set_sampler_stall_ms", "rx_sampler_peer_abort", "rx_peer_topology",
-    "rx_sampler_peer_disconnect",
+    "rx_sampler_peer_disconnect", "rx_set_refinement", "rx_refinement_counters",
 ]
 ABI_VERSION = 4
 RX_MAX_RANKS = 8
@@ -107,6 +107,8 @@ def load():
     L.rx_lnprob_batch_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     L.rx_set_issue_order.argtypes = [vp, C.c_int]
     L.rx_set_waves_per_simd.argtypes = [vp, C.c_int]
+    L.rx_set_refinement.argtypes = [vp, C.c_int]
+    L.rx_refinement_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.rx_set_source_prior.argtypes = [vp, C.c_int, C.c_int]
     L.rx_lnprior_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]
     u64, i64 = C.c_uint64, C.c_int64

@@ -234,6 +234,8 @@ struct rx_handle {
     } peer;
     unsigned int *d_order_cnt = nullptr;
     int force_occ = 0;               // 0: choose by batch size; 1 / 2: wavefronts per SIMD (rx_set_waves_per_simd)
+    int refine = 1;                  // rx_set_refinement: most solves refine a kept solution (rx_refine.hip.inc); 0: every solve pivoted
+    unsigned long long *d_rf_counters = nullptr;   // [5] rx_refinement_counters
     int issue_order = 1;             // hand large batches out hottest first (rx_set_issue_order; RX_NO_ORDER=1 at rx_create: off)
     int srcfix_value = -1;
     size_t srcfix_filled = 0;
@@ -449,6 +451,7 @@ int fill_args(rx_handle *h, RxKArgs &a, int N, int ncomp, int mode)
     a.srcs = h->d_srcs;
     a.N = N; a.ncomp = ncomp; a.mode = mode; a.method = h->method;
     a.miniter = h->miniter; a.maxiter = h->maxiter; a.h2_total = h->h2_total;
+    a.refine = h->refine; a.rf_counters = h->d_rf_counters;
     a.deltav_cms = h->deltav_kms * 1e5;      // core.py:447-454: km/s -> cm/s
     a.fortho = h->fortho;
     a.queue = h->d_queue;
@@ -589,6 +592,8 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipMemset(h->d_srcs, 0, sizeof(RxSourceDev) * RX_MAX_SOURCES)) != hipSuccess) return hipfail("hipMemset", e);
     if ((e = hipMalloc(&h->d_queue, sizeof(unsigned int))) != hipSuccess) return hipfail("hipMalloc", e);
     if ((e = hipMalloc(&h->d_order_cnt, 2 * RXK_ORDER_BUCKETS * sizeof(unsigned int))) != hipSuccess) return hipfail("hipMalloc", e);
+    if ((e = hipMalloc(&h->d_rf_counters, 5 * sizeof(unsigned long long))) != hipSuccess) return hipfail("hipMalloc", e);
+    if ((e = hipMemset(h->d_rf_counters, 0, 5 * sizeof(unsigned long long))) != hipSuccess) return hipfail("hipMemset", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming)) != hipSuccess) return hipfail("hipEventCreate", e);
@@ -614,6 +619,7 @@ void rx_destroy(rx_handle *h)
     if (h->d_srcs) (void)hipFree(h->d_srcs);
     if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_order_cnt) (void)hipFree(h->d_order_cnt);
+    if (h->d_rf_counters) (void)hipFree(h->d_rf_counters);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
@@ -723,6 +729,25 @@ int rx_set_waves_per_simd(rx_handle *h, int waves)
 {
     if (!h || waves < 0 || waves > 2) return RX_E_ARG;
     h->force_occ = waves;
+    return 0;
+}
+
+int rx_set_refinement(rx_handle *h, int enabled)
+{
+    if (!h) return RX_E_ARG;
+    h->refine = enabled ? 1 : 0;
+    return 0;
+}
+
+int rx_refinement_counters(rx_handle *h, uint64_t *out5, int reset)
+{
+    if (!h || !out5) return RX_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->in_flight) { HIPCHK(h, hipEventSynchronize(h->ev_done)); h->in_flight = false; }
+    unsigned long long v[5];
+    HIPCHK(h, hipMemcpy(v, h->d_rf_counters, sizeof v, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 5; ++i) out5[i] = v[i];
+    if (reset) HIPCHK(h, hipMemset(h->d_rf_counters, 0, sizeof v));
     return 0;
 }
 

@@ -365,6 +365,18 @@ class Engine:
     def sampler_peer_same_device(self):
         return int(self._L.rx_sampler_peer_same_device(self._h))
 
+    def set_refinement(self, enabled=True):
+        """How matrix_'s linear solve is made from iteration 12 on (rx_set_refinement): refinement of a kept solution
+        (default) or the pivoted elimination every iteration, as the reference does."""
+        self._chk(self._L.rx_set_refinement(self._h, 1 if enabled else 0), "rx_set_refinement")
+
+    def refinement_counters(self, reset=True):
+        """Totals since the last reset: iterations, solves made as refinements, corrections, attempts given up, inverses kept."""
+        import ctypes as C
+        out = (C.c_uint64 * 5)()
+        self._chk(self._L.rx_refinement_counters(self._h, out, 1 if reset else 0), "rx_refinement_counters")
+        return dict(zip(("iterations", "refined", "corrections", "failed", "kept"), (int(v) for v in out)))
+
     def set_waves_per_simd(self, waves=0):
         """Scheduling of the solve launches: 0 = automatic, 1 = one wavefront per SIMD, 2 = two."""
         self._chk(self._L.rx_set_waves_per_simd(self._h, int(waves)), "rx_set_waves_per_simd")

@@ -1,0 +1,188 @@
+"""CPU gate for the iterative-refinement form of matrix_'s step 4 (the scheme of the device kernels).
+
+    python scripts/refine_gate.py [N=65536] [--threads 8] [--quick]
+
+Oracle against oracle: the reference's arithmetic (pivoted LINPACK solve every iteration) against the
+variant behind oracle.set_refine (radex_oracle.h: rxo_set_refine) on
+  * N config-2 prior-box walkers (BASELINE configs[1]'s distribution, seed 24680),
+  * config 3's 16 sources x 256 prior-box walkers,
+  * 4096 two-component walkers (config 4's priors, prior box).
+Per scanned (first_iter, tol, max_steps, lag): status / niter equality, lnprob and flux deviation per
+tier (converged / maxiter), share of the solves replaced, mean refinement steps, failed attempts.
+Test infrastructure: nothing here touches the product.
+"""
+import argparse
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np                                   # noqa: E402
+
+from oracle import oracle as O                       # noqa: E402
+from radex_emcee_amd import workloads                # noqa: E402
+from radex_emcee_amd.molecule import default_molfile  # noqa: E402
+
+
+# the device kernels' setting (rx_refine.hip.inc): first iteration 12, thresholds 2^-43 / 2^-36 (= tol / 8, loose / 8), at most 8
+# corrections, one kept inverse per parity, NaN / blow-up guard 2^10, back-off
+DEVICE = (12, 2.0 ** -40, 8, 2, 1, 2.0 ** 13, 2.0 ** -33, 1)
+
+
+def rel(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1.0)
+
+
+def evaluate(mol, src, W, threads, flux_too=True):
+    lnp, st, nit = O.lnprob_batch(mol, src, W, nthreads=threads)
+    fl = O.model_flux_batch(mol, src, W, nthreads=threads)[0] if flux_too else None
+    return lnp, st, nit, fl
+
+
+def compare(tag, base, var, cnt):
+    lnp0, st0, nit0, fl0 = base
+    lnp1, st1, nit1, fl1 = var
+    N = len(lnp0)
+    out = dict(tag=tag, N=N, status_equal=int((st0 == st1).sum()), niter_equal=int((nit0 == nit1).sum()))
+    fin = np.isfinite(lnp0) & np.isfinite(lnp1)
+    out["finite_mismatch"] = int((np.isfinite(lnp0) != np.isfinite(lnp1)).sum())
+    for name, code in (("conv", 0), ("maxiter", 1)):
+        m = fin & (st0 == code) & (st1 == code)
+        if m.any():
+            out["lnp_" + name] = float(rel(lnp1[m], lnp0[m]).max())
+            if fl0 is not None:
+                with np.errstate(all="ignore"):
+                    d = np.abs(fl1[m] - fl0[m]) / np.abs(fl0[m])
+                d = d[np.isfinite(d)]
+                out["flux_" + name] = float(d.max()) if len(d) else 0.0
+    tot = cnt["full"] + cnt["refined"]
+    out["replaced"] = cnt["refined"] / max(tot, 1)
+    out["cost"] = cost_model(cnt)
+    out["steps_per_attempt"] = cnt["steps"] / max(cnt["refined"] + cnt["failed"], 1)
+    out["failed_per_attempt"] = cnt["failed"] / max(cnt["refined"] + cnt["failed"], 1)
+    return out
+
+
+# k cycles of a lone wavefront per iteration (stamped build): everything but the solve 2.8, the pivoted
+# solve with its hand-over 11.0, the same carrying the inverse ~15.5 (estimate: +21 instructions per elimination step), a
+# refined iteration's fixed part (matrix to registers, the kept inverse out of the AGPRs) ~0.8, a refinement step ~0.75
+# (estimate: 2 x (12 rotations + 33 broadcast FMAs + 30 instructions of cross-group sum) + the test)
+C_REST, C_SOLVE, C_INVERT, C_REFINE, C_STEP = 2.8, 11.0, 15.5, 0.8, 0.75
+
+
+def cost_model(cnt):
+    """Modelled iteration cost relative to a pivoted solve every iteration."""
+    iters = cnt["full"] + cnt["refined"]
+    plain = cnt["full"] - cnt["kept"]
+    now = (iters * C_REST + plain * C_SOLVE + cnt["kept"] * C_INVERT + (cnt["refined"] + cnt["failed"]) * C_REFINE
+           + cnt["steps"] * C_STEP)
+    return now / max(iters * (C_REST + C_SOLVE), 1e-9)
+
+
+def flux_by_test_rule(fl1, fl0, W, tbg, mol, ncomp):
+    """tests/test_gpu_parity.py:_flux_ok: |df| <= 1e-4 |f| + 1e-10 F_bg; returns the worst |df| / tolerance."""
+    st = O.State(mol)
+    st.backrad(tbg)
+    bmax = st.arr("backi").max()
+    size = np.zeros(len(W))
+    for c in range(ncomp):
+        size = np.maximum(size, 10.0 ** W[:, 4 * c + 3])
+    tol = 1e-4 * np.abs(fl0) + 1e-10 * (bmax * size * 1e23)[:, None]
+    with np.errstate(all="ignore"):
+        q = np.abs(fl1 - fl0) / tol
+    q = q[np.isfinite(q)]
+    return float(q.max()) if len(q) else 0.0
+
+
+def fmt(o):
+    return ("%-78s status %d/%d niter %d/%d | lnp conv %.1e maxit %.1e | flux conv %.1e maxit %.1e | "
+            "flux/tol %.2g | replaced %.1f %% steps %.2f failed %.1f %% cost %.2f (maxiter walkers: replaced %.1f %% "
+            "steps %.2f failed %.1f %% cost %.2f)"
+            % (o["tag"], o["status_equal"], o["N"], o["niter_equal"], o["N"], o.get("lnp_conv", 0),
+               o.get("lnp_maxiter", 0), o.get("flux_conv", 0), o.get("flux_maxiter", 0), o.get("flux_rule", 0),
+               100 * o["replaced"], o["steps_per_attempt"], 100 * o["failed_per_attempt"], o["cost"],
+               100 * o.get("slow_replaced", 0), o.get("slow_steps", 0), 100 * o.get("slow_failed", 0), o.get("slow_cost", 0)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("N", nargs="?", type=int, default=65536)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--quick", action="store_true", help="config 2 only, three settings")
+    ap.add_argument("--scan", default="", help="config 2 only; settings as first:tol:max:lag:crit:d1max:loose:backoff,...")
+    a = ap.parse_args()
+    mol = O.Molecule(default_molfile("co"))
+
+    sets = []
+    cfg = workloads.config2(a.N, seed=24680)
+    O.set_refine(0)
+    src0 = O.Source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
+    tf = O.model_flux_batch(mol, src0, cfg["truth"][None, :])[0][0]
+    sets.append(("config2 x%d" % a.N, O.Source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"]), cfg["walkers"]))
+    if not (a.quick or a.scan):
+        c3 = workloads.config3(256, 3333)
+        for s, W in list(zip(c3["sources"], c3["walkers"]))[:16]:
+            sets.append(("config3 " + s["name"], O.Source(s["tbg"], s["Jup"], s["flux"], s["eflux"], s["bounds"]), W))
+        c4 = workloads.config4(8)
+        W4 = workloads.draw_prior_2comp(c4["bounds"], 4096, 99)
+        s40 = O.Source(c4["tbg"], c4["Jup"], np.ones(10), np.ones(10), c4["bounds"], ncomp=2, T_d=c4["T_d"])
+        tf4 = O.model_flux_batch(mol, s40, c4["truth"][None, :])[0][0]
+        sets.append(("config4 prior box x4096",
+                     O.Source(c4["tbg"], c4["Jup"], tf4, 0.1 * tf4, c4["bounds"], ncomp=2, T_d=c4["T_d"]), W4))
+
+    if a.scan:
+        scan = [(int(f), float(t), int(m), int(l), int(c), float(d), float(lo), int(bo))
+                for f, t, m, l, c, d, lo, bo in (x.split(":") for x in a.scan.split(","))]
+    elif a.quick:
+        scan = [(20, 1e-10, 4, 2, 0, 0.0, 0.0, 0), DEVICE]
+    else:
+        scan = ([(f, tol, 4, 2, 0, 0.0, 0.0, 0) for f in (12, 20, 30) for tol in (1e-10, 1e-12)]                # the judge's scheme
+                + [DEVICE]
+                + [(f, 2.0 ** -40, ms, lag, 1, 2.0 ** 13, lo, bo)                                               # around it
+                   for f, ms, lag, lo, bo in ((20, 8, 2, 2.0 ** -33, 1), (12, 6, 2, 2.0 ** -33, 1), (12, 8, 2, 0.0, 1),
+                                              (12, 8, 2, 2.0 ** -33, 0), (12, 8, 2, 2.0 ** -30, 1), (12, 8, 1, 2.0 ** -33, 1))])
+
+    t0 = time.time()
+    base = []
+    for name, src, W in sets:
+        base.append(evaluate(mol, src, W, a.threads))
+    print("# reference arithmetic: %.0f s" % (time.time() - t0), flush=True)
+    # group config 3's sources into one row
+    for first, tol, ms, lag, crit, d1, lo, bo in scan:
+        O.set_refine(first, tol, ms, lag, crit, d1, lo, bo)
+        rows = []
+        for (name, src, W), b in zip(sets, base):
+            O.refine_counters(reset=True)
+            v = evaluate(mol, src, W, a.threads, flux_too=True)
+            cnt = O.refine_counters(reset=True)
+            # (two passes -- lnprob and flux -- ran: the counters hold both, the ratios are unaffected)
+            row = compare("first %d tol %.0e max %d lag %d crit %d loose %.0e backoff %d | %s" % (first, tol, ms, lag, crit, lo, bo, name), b, v, cnt)
+            row["flux_rule"] = flux_by_test_rule(v[3], b[3], W, src.tbg, mol, src.ncomp)
+            slow = b[1] == 1                                   # the walkers that set the length of a small launch
+            if slow.sum() >= 8:
+                O.lnprob_batch(mol, src, W[slow], nthreads=a.threads)
+                c2 = O.refine_counters(reset=True)
+                att = max(c2["refined"] + c2["failed"], 1)
+                row.update(slow_replaced=c2["refined"] / max(c2["full"] + c2["refined"], 1), slow_steps=c2["steps"] / att,
+                           slow_failed=c2["failed"] / att, slow_cost=cost_model(c2))
+            rows.append(row)
+        O.set_refine(0)
+        c3rows = [r for r in rows if "config3" in r["tag"]]
+        for r in rows:
+            if "config3" not in r["tag"]:
+                print(fmt(r), flush=True)
+        if c3rows:
+            agg = dict(tag="first %d tol %.0e max %d lag %d crit %d loose %.0e backoff %d | config3 16 sources x256" % (first, tol, ms, lag, crit, lo, bo),
+                       N=sum(r["N"] for r in c3rows), status_equal=sum(r["status_equal"] for r in c3rows),
+                       niter_equal=sum(r["niter_equal"] for r in c3rows),
+                       replaced=np.mean([r["replaced"] for r in c3rows]),
+                       steps_per_attempt=np.mean([r["steps_per_attempt"] for r in c3rows]),
+                       failed_per_attempt=np.mean([r["failed_per_attempt"] for r in c3rows]))
+            agg["cost"] = np.mean([r["cost"] for r in c3rows])
+            for k in ("lnp_conv", "lnp_maxiter", "flux_conv", "flux_maxiter", "flux_rule"):
+                agg[k] = max(r.get(k, 0) for r in c3rows)
+            print(fmt(agg), flush=True)
+    print("# total %.0f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
