@@ -311,6 +311,11 @@ def main():
         assert torch.equal(torch.nan_to_num(lnp_all[rank * per:rank * per + nmine], neginf=-1e300),
                            torch.nan_to_num(lnp[:nmine], neginf=-1e300))
 
+    # how the solves of this rank's block were made (rx_refinement_counters): one untimed launch between two resets
+    eng.refinement_counters(reset=True)
+    step()
+    torch.cuda.synchronize()
+    rfc = eng.refinement_counters(reset=True)
     # kernel time from HIP events recorded on the launch stream (inside the library): this rank's block
     kreps = max(5, min(50, args.steps))
     kms = eng.time_lnprob_torch(P, lnp[:nmine], st, nit, reps=kreps, stream=stream) if nmine else 0.0
@@ -375,7 +380,7 @@ def main():
                       "walker-lnlike evals/sec (1024 walkers, CO 1-comp) at 1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "evals/s", "n_gpus": n_confirmed, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": None if world == 1 else "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic CO SLED J=1..10, 1-component, "
                                    "%d walkers uniform in the prior box (seed 1234), z=2.5" % nw
@@ -395,6 +400,14 @@ def main():
                          "fp64_valu": {"bound": "fp64-valu", "achieved": round(fl / (kms * 1e-3) / 1e12, 4),
                                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": fl / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
+            "refinement": {"iterations": rfc["iterations"], "solves_made_as_refinements": rfc["refined"],
+                           "share": round(rfc["refined"] / max(rfc["iterations"], 1), 4),
+                           "corrections_per_attempt": round(rfc["corrections"] / max(rfc["refined"] + rfc["failed"], 1), 2),
+                           "attempts_given_up": rfc["failed"], "inverses_kept": rfc["kept"],
+                           "note": "from iteration 12 on a solve is a refinement of the solution of two iterations back against a kept "
+                                   "inverse (a few 41 x 41 matrix-vector products) with the pivoted elimination as the fall-back "
+                                   "(rx_set_refinement); fp64_valu below still prices EVERY iteration at the reference's "
+                                   "algorithmic flops (SURVEY 8d: 2/3 n^3 + 7 n^2 + 60 L), which a refined solve does not execute"},
             "fp64": {"achieved_tflops": round(fl / (kms * 1e-3) / 1e12, 4),
                      "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
                      "frac": fl / (kms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
@@ -471,13 +484,15 @@ def main():
                     smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src)
                     state = smp.run_mcmc(c["walkers"], 1, store=False)
                     torch.cuda.synchronize()
-                    eng.sampler_stats(True)
-                    ts = time.perf_counter()
+                    ts = time.perf_counter()                          # (timed like the multi-GPU schedules: kernel counters off)
                     fin1 = smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
                     torch.cuda.synchronize()
                     d1 = time.perf_counter() - ts
-                    st1 = eng.sampler_stats(False)
                     sha1_one = state_sha1(fin1)
+                    eng.sampler_stats(True)                           # the counters: another run of the same length, untimed
+                    smp.run_mcmc(State(state.coords, state.log_prob), nst, store=False)
+                    torch.cuda.synchronize()
+                    st1 = eng.sampler_stats(False)
                     del smp
                 d1 = max_over_ranks(d1)
                 rec["one_gpu_dataflow"] = entry(d1, "dataflow: one persistent kernel on ONE GPU (rank 0 alone)", "none",

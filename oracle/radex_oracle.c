@@ -471,10 +471,19 @@ static int rf_solve(rxo_state *s, int niter)
             double xj = xx[j]; const double *col = a + (size_t)j * n;
             for (int i = 0; i < n; i++) r[i] -= col[i] * xj;
         }
-        for (int i = 0; i < n; i++) d[i] = 0.0;
-        for (int j = 0; j < n; j++) {
-            double rj = r[j]; const double *col = Mi + (size_t)j * n;
-            for (int i = 0; i < n; i++) d[i] += col[i] * rj;
+        if (RF_CRIT >= 1) {
+            /* the device forms the correction in single precision (it only has to be good to a few digits) */
+            for (int i = 0; i < n; i++) {
+                float acc = 0.0f;
+                for (int j = 0; j < n; j++) acc += (float)Mi[i + (size_t)j * n] * (float)r[j];
+                d[i] = (double)acc;
+            }
+        } else {
+            for (int i = 0; i < n; i++) d[i] = 0.0;
+            for (int j = 0; j < n; j++) {
+                double rj = r[j]; const double *col = Mi + (size_t)j * n;
+                for (int i = 0; i < n; i++) d[i] += col[i] * rj;
+            }
         }
         double dmax = 0.0;
         int32_t hd = 0;
@@ -534,6 +543,7 @@ static int rf_solve(rxo_state *s, int niter)
         return 0;
     }
     s->rf_frun = 0;
+
     memcpy(s->rhs, xx, sizeof(double) * n);
     memcpy(s->rf_x[p], xx, sizeof(double) * n);
     s->lu_info = 0;

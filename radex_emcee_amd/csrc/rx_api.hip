@@ -227,6 +227,7 @@ struct rx_handle {
         char *base[RX_MAX_RANKS] = {};
         bool opened[RX_MAX_RANKS] = {};          // mapped with hipIpcOpenMemHandle (to be closed)
         char **d_bases = nullptr;                // device copy of base[]
+        uint32_t *d_touch = nullptr;             // destination of rx_sampler_peer_connect's one-word reads of the peers' blocks
         unsigned long long off_version = 0, off_done = 0, off_abort = 0, off_alive = 0, off_lnp = 0, off_nacc = 0, off_hist = 0, off_pend = 0, off_pendver = 0;
         bool connected = false, begun = false;
         int same_device = 1;                     // ranks whose replica lives on THIS device (own included): they share its CUs
@@ -234,8 +235,10 @@ struct rx_handle {
     } peer;
     unsigned int *d_order_cnt = nullptr;
     int force_occ = 0;               // 0: choose by batch size; 1 / 2: wavefronts per SIMD (rx_set_waves_per_simd)
+    int small_grid = 1;              // launch(): batches of at most 2 x num_cu items get one workgroup per item (RX_SMALL_GRID=0: ceil(items / 4))
     int refine = 1;                  // rx_set_refinement: most solves refine a kept solution (rx_refine.hip.inc); 0: every solve pivoted
     unsigned long long *d_rf_counters = nullptr;   // [5] rx_refinement_counters
+    float *d_rf_gmem = nullptr;      // the two-wavefront CO kernels' kept inverses: [largest grid x wavefronts][2][rf_minv_floats]
     int issue_order = 1;             // hand large batches out hottest first (rx_set_issue_order; RX_NO_ORDER=1 at rx_create: off)
     int srcfix_value = -1;
     size_t srcfix_filled = 0;
@@ -451,7 +454,7 @@ int fill_args(rx_handle *h, RxKArgs &a, int N, int ncomp, int mode)
     a.srcs = h->d_srcs;
     a.N = N; a.ncomp = ncomp; a.mode = mode; a.method = h->method;
     a.miniter = h->miniter; a.maxiter = h->maxiter; a.h2_total = h->h2_total;
-    a.refine = h->refine; a.rf_counters = h->d_rf_counters;
+    a.refine = h->refine; a.rf_counters = h->d_rf_counters; a.rf_gmem = h->d_rf_gmem;
     a.deltav_cms = h->deltav_kms * 1e5;      // core.py:447-454: km/s -> cm/s
     a.fortho = h->fortho;
     a.queue = h->d_queue;
@@ -497,6 +500,10 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     const int ncomp = (a.mode == RXK_MODE_SOLVE) ? 1 : a.ncomp;
     const long items = (long)a.N * ncomp;
     long blocks = (items + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK;
+    // a batch of at most half the chip's wavefronts: one workgroup per walker up to the number of compute units, so that the
+    // kernel's first-item rule (a workgroup's wavefront 0 first, see rx_solve_kernel) puts ONE walker on a compute unit before
+    // any unit gets a second one -- walkers that share a unit slow each other down (a rank's block of a strong-scaled ensemble)
+    if (h->small_grid && items <= 2L * h->num_cu) blocks = std::min<long>(items, h->num_cu);
     // one wavefront per SIMD (6.1 us per iteration each) up to ~5 rounds of the chip, then the 2-wave/SIMD
     // build (two at 10.5 us): measured crossover between 4096 and 6144 walkers (scripts/occ_crossover.py) --
     // below it the launch is mostly the 200-iteration walkers, which run faster alone on their SIMD
@@ -598,10 +605,16 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming)) != hipSuccess) return hipfail("hipEventCreate", e);
     { const char *no = getenv("RX_NO_ORDER"); h->issue_order = (no && *no && *no != '0') ? 0 : 1; }   // read once
+    { const char *sg = getenv("RX_SMALL_GRID"); h->small_grid = (sg && *sg == '0') ? 0 : 1; }         // (A/B of the rule in launch())
     int nb = 0;
     kernel_fn k = kernel_for(h->NL, 2, is_exact(h));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
         h->blocks_per_cu2 = std::min(nb, 2);
+    if (rxk::refine_compiled(h->NL, is_exact(h), 2) && h->blocks_per_cu2 >= 2) {
+        // (no launch of a two-wavefront kernel has more workgroups than this: launch(), rx_sampler_run_async_device, peer_launch_shape)
+        const size_t waves = (size_t)h->num_cu * h->blocks_per_cu2 * RXK_WAVES_PER_BLOCK;
+        if ((e = hipMalloc(&h->d_rf_gmem, waves * 2 * rxk::rf_minv_floats(h->NL) * sizeof(float))) != hipSuccess) return hipfail("hipMalloc", e);
+    }
     char nm[64];
     snprintf(nm, sizeof nm, "rx_solve_kernel<%d, 1, %s>", h->NL, is_exact(h) ? "true" : "false");
     h->kname = nm;
@@ -620,6 +633,7 @@ void rx_destroy(rx_handle *h)
     if (h->d_queue) (void)hipFree(h->d_queue);
     if (h->d_order_cnt) (void)hipFree(h->d_order_cnt);
     if (h->d_rf_counters) (void)hipFree(h->d_rf_counters);
+    if (h->d_rf_gmem) (void)hipFree(h->d_rf_gmem);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
@@ -1204,6 +1218,7 @@ int rx_sampler_peer_close(rx_handle *h)
     for (int r = 0; r < RX_MAX_RANKS; ++r)
         if (P.opened[r] && P.base[r]) (void)hipIpcCloseMemHandle(P.base[r]);
     if (P.d_bases) (void)hipFree(P.d_bases);
+    if (P.d_touch) (void)hipFree(P.d_touch);
     if (P.own) (void)hipFree(P.own);
     P = rx_handle::Peer();
     return 0;
@@ -1275,20 +1290,37 @@ int rx_sampler_peer_connect(rx_handle *h, const void *ipc_handles, void *const *
         if (!P.base[r]) { h->err = "rx_sampler_peer_connect: a peer's replica is missing"; return RX_E_ARG; }
     // the per-device registry of this run: which replicas live on THIS device (two handles of one process, ranks of a
     // rehearsal squeezed onto one GPU).  A mapping whose device cannot be told counts as remote.
+    // Every peer block must be reachable from THIS device: a task stores its result into all replicas, and a store into memory
+    // the device cannot reach faults and takes the process down.  The library asks itself (the caller's own check needs every
+    // rank to see every device, which one-GPU-per-process launches do not): the device a mapping lives on, then
+    // hipDeviceCanAccessPeer.  A mapping whose device cannot be told is treated as unreachable -> RX_E_UNSUPP, and the
+    // caller falls back to half-steps + all-gather on all ranks.
     P.same_device = 0;
     for (int r = 0; r < P.nranks; ++r) {
         hipPointerAttribute_t at;
         if (r == P.rank) { ++P.same_device; continue; }
-        if (hipPointerGetAttributes(&at, P.base[r]) == hipSuccess) { if (at.device == h->device) ++P.same_device; }
-        else (void)hipGetLastError();
+        if (hipPointerGetAttributes(&at, P.base[r]) != hipSuccess) {
+            (void)hipGetLastError();
+            h->err = "rx_sampler_peer_connect: cannot tell which device a peer's replica lives on";
+            return RX_E_UNSUPP;
+        }
+        if (at.device == h->device) { ++P.same_device; continue; }
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, h->device, at.device) != hipSuccess || !can) {
+            (void)hipGetLastError();
+            h->err = "rx_sampler_peer_connect: this device has no peer access to the device of rank " + std::to_string(r);
+            return RX_E_UNSUPP;
+        }
     }
     if (!P.d_bases) HIPCHK(h, hipMalloc(&P.d_bases, RX_MAX_RANKS * sizeof(char *)));
     HIPCHK(h, hipMemcpy(P.d_bases, P.base, RX_MAX_RANKS * sizeof(char *), hipMemcpyHostToDevice));
     // The mappings were opened with hipIpcMemLazyEnablePeerAccess: whatever the first access from this device sets up is set
     // up HERE, by reading one word of every peer's block (a read: harmless whatever the peer is doing), not inside the first
     // launch under the no-progress watchdog
+    // (into a word of its own: d_queue is the live task counter of whatever this handle may still have running)
+    if (!P.d_touch) HIPCHK(h, hipMalloc(&P.d_touch, sizeof(uint32_t)));
     for (int r = 0; r < P.nranks; ++r)
-        if (r != P.rank) HIPCHK(h, hipMemcpy(h->d_queue, P.base[r] + P.off_abort, sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        if (r != P.rank) HIPCHK(h, hipMemcpy(P.d_touch, P.base[r] + P.off_abort, sizeof(uint32_t), hipMemcpyDeviceToDevice));
     P.connected = true;
     return 0;
 }

@@ -92,6 +92,7 @@ struct RxKArgs {
     int32_t h2_total;               // data file lists 'H2' (id 1): density[0] = pH2+oH2 (core.py:551-554)
     int32_t refine;                 // != 0: most solves from iteration 12 on refine a kept solution (rx_refine.hip.inc); 0: every solve pivoted
     int32_t pad2_;
+    float *rf_gmem;                 // two-wavefronts-per-SIMD CO kernels: [grid wavefronts][2] kept inverses (rx_refine.hip.inc); null: no refinement there
     unsigned long long *rf_counters;// optional [5]: iterations, solves replaced, corrections, attempts given up, inverses kept (atomics)
     double deltav_cms, fortho;
     // RXK_MODE_SOLVE inputs

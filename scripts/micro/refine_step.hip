@@ -16,12 +16,14 @@ constexpr int NL = 41, RB = Lay2<NL>::RB, CJ = Lay2<NL>::CJ;
 __global__ __launch_bounds__(64, 1) void k_refine(const double *A, const double *Mi, const double *x0, double *xout, int *info,
                                                  unsigned long long *ticks, int reps)
 {
-    constexpr int S = lds_stride(NL), MS = rf_minv_stride(NL);
+    constexpr int S = lds_stride(NL);
     __shared__ __attribute__((aligned(16))) double sA[(NL + 1) * S];
-    __shared__ __attribute__((aligned(16))) float sM[NL * MS];
+    __shared__ __attribute__((aligned(16))) float sM[rf_minv_floats(NL)];
     const int lane = threadIdx.x;
     for (int i = lane; i < (NL + 1) * S; i += 64) { const int r = i / S, j = i % S; sA[i] = (r < NL && j < NL) ? A[r * NL + j] : 0.0; }
-    for (int i = lane; i < NL * MS; i += 64) { const int r = i / MS, j = i % MS; sM[i] = j < NL ? (float)Mi[r * NL + j] : 0.0f; }
+    for (int i = lane; i < rf_minv_floats(NL); i += 64) sM[i] = 0.0f;
+    __syncthreads();
+    for (int i = lane; i < NL * NL; i += 64) sM[rf_minv_index(NL, i / NL, i % NL)] = (float)Mi[i];
     __syncthreads();
     const bool isrow = lane < NL;
     const double x = isrow ? x0[lane] : 0.0, nb = (lane == NL - 1) ? -1.0 : 0.0;
@@ -31,14 +33,15 @@ __global__ __launch_bounds__(64, 1) void k_refine(const double *A, const double 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
 #pragma nounroll
     for (int r = 0; r < reps; ++r) {
-        double arow[NL], mrow[NL];
+        double arow[NL];
+        float mrow[NL];
         int li = isrow ? lane : NL;
         asm volatile("" : "+v"(li));
         rf_load_row<NL>(sA, li, arow);                       // (per call, like an iteration of the kernel does)
         rf_load_minv<NL>(sM, li < NL ? li : NL - 1, mrow);
         double xx = x;
         asm volatile("" : "+v"(xx));
-        ok = rf_refine<NL>(arow, mrow, nb, xx, (1ull << NL) - 1ull, steps);
+        ok = rf_refine<NL, false>(arow, sA, mrow, nb, xx, (1ull << NL) - 1ull, steps);
         if (r == reps - 1 && isrow) xout[lane] = xx;
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -57,15 +60,17 @@ __device__ __forceinline__ void rowdot_multi(const double (&row)[NL], const doub
 template <int PART>
 __global__ __launch_bounds__(64, 1) void k_part(const double *A, double *xout, unsigned long long *ticks)
 {
-    constexpr int S = lds_stride(NL), MS = rf_minv_stride(NL);
+    constexpr int S = lds_stride(NL);
     __shared__ __attribute__((aligned(16))) double sA[(NL + 1) * S];
-    __shared__ __attribute__((aligned(16))) float sM[NL * MS];
+    __shared__ __attribute__((aligned(16))) float sM[rf_minv_floats(NL)];
     const int lane = threadIdx.x;
     for (int i = lane; i < (NL + 1) * S; i += 64) sA[i] = A[i % (NL * NL)];
-    for (int i = lane; i < NL * MS; i += 64) sM[i] = (float)A[i % (NL * NL)];
+    for (int i = lane; i < rf_minv_floats(NL); i += 64) sM[i] = (float)A[i % (NL * NL)];
     __syncthreads();
-    double row[NL], mrow[NL], x = A[lane], y = 0.0, xr[3] = {x, x, x};
+    double row[NL], x = A[lane], y = 0.0, xr[3] = {x, x, x};
+    float mrow[NL], y32 = 0.0f, xr32[3] = {(float)x, (float)x, (float)x};
     rf_load_row<NL>(sA, lane % NL, row);
+    rf_load_minv<NL>(sM, lane % NL, mrow);
     unsigned long long t0, t1;
     int acc = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -74,6 +79,8 @@ __global__ __launch_bounds__(64, 1) void k_part(const double *A, double *xout, u
         if (PART == 0) { rf_replicate(x, xr); x = xr[0] + xr[1] + xr[2]; }
         if (PART == 1) { rf_rowdot<NL>(row, xr, y); }
         if (PART == 2) { acc += rf_hi_max(x, true); x += (double)acc; }
+        if (PART == 7) { rf_rowdot32<NL>(mrow, xr32, y32); }
+        if (PART == 8) { rf_replicate32(y32, xr32); y32 = xr32[0] + xr32[1] + xr32[2]; }
         if (PART == 4) { double a1[1] = {y}; rowdot_multi<1>(row, xr, a1); y = a1[0]; }
         if (PART == 5) { double a2[2] = {y, 0.0}; rowdot_multi<2>(row, xr, a2); y = a2[0] + a2[1]; }
         if (PART == 6) { double a4[4] = {y, 0.0, 0.0, 0.0}; rowdot_multi<4>(row, xr, a4); y = (a4[0] + a4[1]) + (a4[2] + a4[3]); }
@@ -84,12 +91,12 @@ __global__ __launch_bounds__(64, 1) void k_part(const double *A, double *xout, u
 #pragma unroll
             for (int j = 0; j < NL; ++j) asm volatile("" : "+v"(row[j]), "+v"(mrow[j]));
         }
-        asm volatile("" : "+v"(x), "+v"(y));
+        asm volatile("" : "+v"(x), "+v"(y), "+v"(y32));
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     if (lane == 0) ticks[0] = t1 - t0;
-    double sum = x + y + xr[0] + xr[1] + xr[2] + acc;
-    for (int j = 0; j < NL; ++j) sum += row[j] + (PART == 3 ? mrow[j] : 0.0);
+    double sum = x + y + xr[0] + xr[1] + xr[2] + acc + y32 + xr32[0];
+    for (int j = 0; j < NL; ++j) sum += row[j] + mrow[j];
     xout[lane] = sum;
 }
 
@@ -157,6 +164,8 @@ int main()
         PART(1, "product (41 v_fmac_f64_dpp)")
         PART(2, "high-word maximum of a vector")
         PART(3, "a row of A and of the kept inverse from LDS")
+        PART(7, "single-precision product (41 v_fmac_f32_dpp)")
+        PART(8, "replication of a single-precision vector")
         PART(4, "product, one statement per FMA, 1 accumulator")
         PART(5, "product, one statement per FMA, 2 accumulators")
         PART(6, "product, one statement per FMA, 4 accumulators")

@@ -10,15 +10,18 @@ eng = Engine()
 cfg = workloads.config2(32768, seed=5678)
 tf = np.ones(10)
 eng.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"])
-for occ, on in ((2, False), (1, False), (1, True)):
+for occ, on in ((2, False), (2, True), (1, False), (1, True)):
     eng.set_waves_per_simd(occ); eng.set_refinement(on)
     eng.lnprob_batch(cfg["walkers"])
     ts = []
     for _ in range(7):
         t = time.perf_counter(); eng.lnprob_batch(cfg["walkers"]); ts.append(time.perf_counter() - t)
-    print("32768 walkers, %d wavefront(s) per SIMD, refinement %-3s: %.2f ms per launch (host-timed median)" % (occ, "on" if on else "off", 1e3 * np.median(ts)))
+    eng.refinement_counters(reset=True); lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True); c = eng.refinement_counters()
+    import hashlib
+    print("32768 walkers, %d wavefront(s) per SIMD, refinement %-3s: %.2f ms per launch (host-timed median); refined %.1f %% of %d iterations; sha1 of lnprob %s"
+          % (occ, "on" if on else "off", 1e3 * np.median(ts), 100.0 * c["refined"] / max(c["iterations"], 1), c["iterations"], hashlib.sha1(lnp.tobytes()).hexdigest()[:12]))
 c5 = workloads.config2(65536, seed=5678)
-for occ, on in ((2, False), (1, True)):
+for occ, on in ((2, False), (2, True), (1, True)):
     eng.set_waves_per_simd(occ); eng.set_refinement(on)
     d = DeviceEnsembleSampler(65536, 4, engine=eng, seed=1)
     st = d.run_mcmc(c5["walkers"], 4, store=False)

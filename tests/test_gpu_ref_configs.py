@@ -52,7 +52,7 @@ def _check_solves(tag, r, niter, conv, sb, backi):
     tol = np.where(settled, 1e-4, 1e-3) * np.abs(sb) + floor
     ok = (d <= tol) | both_nan
     assert ok.all(), (tag, np.argwhere(~ok)[:5], (d / tol)[~ok][:5])
-    sig = settled & (np.abs(sb) > 1e-6 * np.nanmax(np.abs(sb), axis=1, keepdims=True)) & np.isfinite(sb)
+    sig = settled & (1e-4 * np.abs(sb) > 100.0 * floor) & np.isfinite(sb)        # (where the background floor plays no part)
     rel = d[sig] / np.abs(sb[sig])
     print("%s: %d solves, iteration count equal on %d; surface brightness of the settled walkers vs the reference binary: "
           "median %.1e, worst %.1e; walkers at maxiter: %d, worst %.1e"
