@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 4
+#define RX_ABI_VERSION 5
 #define RX_MAX_SOURCES 64      /* sources resident in one handle (config 3: 16) */
 #define RX_MAX_NJ      32      /* observed lines per source                     */
 #define RX_MAX_LEVELS  64      /* one level per lane of a 64-wide wavefront     */

@@ -32,7 +32,7 @@ EXPORTS = [
     "rx_sampler_peer_same_device", "rx_set_sampler_stall_ms", "rx_sampler_peer_abort", "rx_peer_topology",
     "rx_sampler_peer_disconnect", "rx_set_refinement", "rx_refinement_counters",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 RX_MAX_RANKS = 8
 RX_IPC_HANDLE_BYTES = 64
 
@@ -59,7 +59,7 @@ def kernel_source_sha256() -> str:
     measured on other kernel sources."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rx_kernel.hip.inc", "rx_sampler.hip.inc", "rx_tables.h"):
+    for f in ("rx_kernel.hip.inc", "rx_refine.hip.inc", "rx_sampler.hip.inc", "rx_tables.h"):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     with open(os.path.join(CSRC, "Makefile")) as fh:          # the compiler flags of the product library

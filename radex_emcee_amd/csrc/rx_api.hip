@@ -1149,7 +1149,10 @@ int rx_sampler_run_async_device(rx_handle *h, int nens, int nwalkers, int ncomp,
     A.chain = d_chain; A.chain_lnp = d_chain_lnp;
     A.timeout_ticks = h->sampler_timeout_ticks;
     A.stall_ticks = h->sampler_stall_ticks;
-    A.stats = (h->stats_on && blocks * RXK_WAVES_PER_BLOCK <= rxs::RXS_STAT_SLOTS) ? h->d_stats : nullptr;   // (one slot per wavefront)
+    if (h->stats_on && blocks * RXK_WAVES_PER_BLOCK > rxs::RXS_STAT_SLOTS) {       // (one slot per wavefront: never silently off)
+        h->err = "rx_sampler_stats: the grid has more wavefronts than counter slots"; return RX_E_UNSUPP;
+    }
+    A.stats = h->stats_on ? h->d_stats : nullptr;
     A.speculate = (occ == 1) && h->speculation != 0;        // (the head start exists in the one-wavefront-per-SIMD build only)
     if (A.speculate) { A.pend = h->w_pend.p; A.pend_version = h->w_pendver.p; }    // (proposals are published only for head starts)
     HIPCHK(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), st));
@@ -1387,7 +1390,10 @@ int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, in
     A.timeout_ticks = h->sampler_timeout_ticks;
     A.stall_ticks = h->sampler_stall_ticks;
     A.alive = (uint32_t *)(P.own + P.off_alive);
-    A.stats = (h->stats_on && blocks * RXK_WAVES_PER_BLOCK <= rxs::RXS_STAT_SLOTS) ? h->d_stats : nullptr;   // (one slot per wavefront)
+    if (h->stats_on && blocks * RXK_WAVES_PER_BLOCK > rxs::RXS_STAT_SLOTS) {       // (one slot per wavefront: never silently off)
+        h->err = "rx_sampler_stats: the grid has more wavefronts than counter slots"; return RX_E_UNSUPP;
+    }
+    A.stats = h->stats_on ? h->d_stats : nullptr;
     A.speculate = (occ == 1) && h->speculation != 0;
     if (A.speculate) { A.pend = (double *)(P.own + P.off_pend); A.pend_version = (uint32_t *)(P.own + P.off_pendver); }
     // (nranks = 1 runs the very same kernel in its one-GPU form on the replica block)

@@ -665,9 +665,10 @@ class DeviceEnsembleSampler:
             raise EngineError("multi-GPU dataflow sampler, rank %d: %s" % bad[0])
         err, timed_out = None, False
         try:
-            if os.environ.get("RX_TEST_INJECT_PEER_ERROR") == str(self.rank):     # (tests: a launch failure on one rank)
-                raise EngineError("injected launch failure (RX_TEST_INJECT_PEER_ERROR)", -5)
-            if os.environ.get("RX_TEST_INJECT_PEER_STALL") != str(self.rank):     # (tests: a rank whose kernel never starts)
+            inject = getattr(self, "_inject", None)              # (set by tests/test_gpu_peer.py's worker only: never read from the environment)
+            if inject == ("error", self.rank):                   # a launch failure on one rank
+                raise EngineError("injected launch failure (test)", -5)
+            if inject != ("stall", self.rank):                   # ("stall": a rank whose kernel never starts)
                 eng.sampler_peer_run(self.a, self.seed, self.step_counter, nsteps, dev, chain, chain_lnp, ens_src=self.ens_src)
         except EngineError as exc:
             err = "sampler_peer_run: %s" % exc
@@ -744,7 +745,10 @@ class DeviceEnsembleSampler:
         allsame = all(r[0] for r in res) and len({r[2] for r in res}) == 1
         self.peer_verified = bool(allsame)
         self.peer_verify_detail = {"steps": k, "ranks_identical": [bool(r[0]) for r in res], "peer_run_completed": [bool(r[1]) for r in res],
-                                   "halfstep_state_sha1": [r[2] for r in res]}
+                                   "halfstep_state_sha1": [r[2] for r in res],
+                                   "outcome": "identical" if allsame else
+                                              ("abandoned by the watchdog on rank(s) %s (nothing was compared there)"
+                                               % [i for i, r in enumerate(res) if not r[1]] if not all(r[1] for r in res) else "differed")}
         return self.peer_verified
 
     # --- sampling ---------------------------------------------------------------------------------------
@@ -786,8 +790,8 @@ class DeviceEnsembleSampler:
                                 ("peer replicas unavailable: %s" % self.peer_state) if isinstance(self.peer_state, str) else None)
         if peer and self.peer_verified is None and self.verify_peer_steps > 0 and self.world > 1:
             if not self._verify_peer():
-                self.peer_state = "the peer-write chain differed from the half-step chain in the first %d steps (%s)" % (
-                    self.verify_peer_steps, self.peer_verify_detail)
+                self.peer_state = "the verification of the peer-write chain against the half-step chain over the first %d steps: %s (%s)" % (
+                    self.verify_peer_steps, self.peer_verify_detail["outcome"], self.peer_verify_detail)
                 self.schedule_reason = self.peer_state
                 if self.rank == 0:
                     import warnings

@@ -201,7 +201,10 @@ else:
     e.set_source(cfg["tbg"], cfg["Jup"], tf, 0.1 * tf, cfg["bounds"], 2, cfg["T_d"])
 d = DeviceEnsembleSampler(nw, 4 * ncomp, engine=e, seed=5, group=dist.group.WORLD, nens=nens, ens_src=ens_src, schedule="dataflow")
 d.fallback = False                                     # a timeout is a failure here, not a silent half-step run
+if os.environ.get("RX_TEST_INJECT_PEER_ERROR"):        # (this worker's own switches: the sampler itself reads no environment variable)
+    d._inject = ("error", int(os.environ["RX_TEST_INJECT_PEER_ERROR"]))
 if os.environ.get("RX_TEST_INJECT_PEER_STALL"):        # (the stall test: the watchdog path IS the expected one, and quick)
+    d._inject = ("stall", int(os.environ["RX_TEST_INJECT_PEER_STALL"]))
     d.fallback = True
     d.verify_peer_steps = 0
     e.set_sampler_timeout_ms(1500.0)
