@@ -504,10 +504,11 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     // kernel's first-item rule (a workgroup's wavefront 0 first, see rx_solve_kernel) puts ONE walker on a compute unit before
     // any unit gets a second one -- walkers that share a unit slow each other down (a rank's block of a strong-scaled ensemble)
     if (h->small_grid && items <= 2L * h->num_cu) blocks = std::min<long>(items, h->num_cu);
-    // one wavefront per SIMD (6.1 us per iteration each) up to ~5 rounds of the chip, then the 2-wave/SIMD
-    // build (two at 10.5 us): measured crossover between 4096 and 6144 walkers (scripts/occ_crossover.py) --
-    // below it the launch is mostly the 200-iteration walkers, which run faster alone on their SIMD
-    int occ = (items > 5L * h->num_cu * RXK_WAVES_PER_BLOCK && h->blocks_per_cu2 >= 2) ? 2 : 1;
+    // one wavefront per SIMD up to ~7 rounds of the chip, then the two-wavefront build: measured crossover between 6144 and 8192
+    // walkers with the refinement (scripts/occ_crossover.py, round 5: 6144 walkers 1.64 against 1.78 ms, 8192 walkers 1.88 against
+    // 1.73) -- below it a launch is mostly its 200-iteration walkers, which run faster alone on their SIMD.  (Both builds give
+    // the same bits: the choice is scheduling only.)
+    int occ = (items > 7L * h->num_cu * RXK_WAVES_PER_BLOCK && h->blocks_per_cu2 >= 2) ? 2 : 1;
     if (h->force_occ == 1 || (h->force_occ == 2 && h->blocks_per_cu2 >= 2)) occ = h->force_occ;
     const long cap = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     if (blocks > cap) blocks = cap;
