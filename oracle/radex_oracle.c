@@ -499,13 +499,13 @@ static int rf_solve(rxo_state *s, int niter)
             if (dmax <= RF_TOL * xmax0) { ok = 1; break; }
         } else {
             /* The device kernels' rule (rx_refine.hip.inc: rf_refine).  Populations sum to 1, so the largest component of
-             * x lies in [1/nlev, 1]: thresholds are absolute, thr = tol / 8 (2^-43 for tol = 2^-40), first correction
-             * d1max / 8.  A correction below thr says the iterate BEFORE it was that good and the one after it better
-             * by the contraction -- provided the iteration contracts: from the fifth correction on the last observed ratio
-             * must be <= 1/2 (D >= 1 in the units of rf_hi; extrapolating the error from the ratio was tried and is
-             * unsafe: the first ratios belong to the fast modes).  Give up at once when the first correction is large
-             * (or NaN), later when a step gains nothing or the gap G cannot be closed in the steps that are left at the
-             * last rate.  The maximum itself (a wave reduction on the device) is only formed from the fourth correction on. */
+             * x lies in [1/nlev, 1]: thresholds are absolute, thr = tol / 8 (2^-43 for tol = 2^-40), loose = loose / 8, the
+             * first correction's blow-up guard d1max / 8.  Accept when every component of a correction is below thr (the
+             * iterate BEFORE it was that good, the one after it better by the contraction), or when two corrections in a
+             * row are below loose (the floor of double-precision residuals for an ill-conditioned system).  Give up at once
+             * when the first correction is large (or NaN); at the sixth and the eighth correction when the last two gained
+             * nothing or the gap G to thr cannot be closed in the corrections that are left at their rate.  (Extrapolating
+             * the error from the ratio of two corrections was tried and is unsafe: the first ratios belong to the fast modes.) */
             const double thr = RF_TOL * 0.125, thr1 = RF_D1MAX > 0.0 ? RF_D1MAX * 0.125 : INFINITY;
             const double loose = RF_LOOSE > 0.0 ? RF_LOOSE * 0.125 : 0.0;
             int big = 0, big1 = 0, bigl = 0;
@@ -514,23 +514,19 @@ static int rf_solve(rxo_state *s, int niter)
                 if (!(fabs(d[i]) < thr1)) big1 = 1;
                 if (!(fabs(d[i]) < loose)) bigl = 1;
             }
-            /* two corrections in a row below the loose bound: the iterate sits on the floor of what double precision
-             * residuals can resolve for this matrix (cond x 1e-16, where the pivoted solve's own answer sits too) */
+            if (!big) { ok = 1; break; }
             if (!bigl && !lprev) { ok = 1; break; }
             lprev = bigl;
             if (getenv("RXO_RF_TRACE")) fprintf(stderr, "RF %d %d %.3e %.3e\n", niter, st, dmax / xmax0, st ? dmax / dprev : 0.0);
-            const int32_t D = hprev - hd;
-            if (!big && (st < 4 || D >= (1 << 20))) { ok = 1; break; }
-            if (st == 0 && big1) break;
-            if (st >= 3) {
-                if (hd >= 0x7ff00000) break;                               /* inf / NaN */
-                if (st >= 4) {
-                    const int32_t G = hd - rf_hi(thr);
-                    if (D <= 0 || (long long)(RF_MAXSTEPS - 1 - st) * D < (G > 0 ? G : 1)) break;
-                }
-                hprev = hd;
-            }
             dprev = dmax;
+            if (st == 0) { if (big1) break; continue; }
+            if (st < 3 || ((st - 3) & 1)) continue;
+            if (hd >= 0x7ff00000) break;                                   /* inf / NaN */
+            if (st > 3) {
+                const int32_t D2 = hprev - hd, G = hd - rf_hi(thr);
+                if (D2 <= 0 || (long long)(RF_MAXSTEPS - 1 - st) * D2 < 2ll * (G > 0 ? G : 1)) break;
+            }
+            hprev = hd;
         }
     }
     s->rf_steps += steps;

@@ -235,7 +235,6 @@ struct rx_handle {
     } peer;
     unsigned int *d_order_cnt = nullptr;
     int force_occ = 0;               // 0: choose by batch size; 1 / 2: wavefronts per SIMD (rx_set_waves_per_simd)
-    int small_grid = 1;              // launch(): batches of at most 2 x num_cu items get one workgroup per item (RX_SMALL_GRID=0: ceil(items / 4))
     int refine = 1;                  // rx_set_refinement: most solves refine a kept solution (rx_refine.hip.inc); 0: every solve pivoted
     unsigned long long *d_rf_counters = nullptr;   // [5] rx_refinement_counters
     float *d_rf_gmem = nullptr;      // the two-wavefront CO kernels' kept inverses: [largest grid x wavefronts][2][rf_minv_floats]
@@ -500,10 +499,6 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     const int ncomp = (a.mode == RXK_MODE_SOLVE) ? 1 : a.ncomp;
     const long items = (long)a.N * ncomp;
     long blocks = (items + RXK_WAVES_PER_BLOCK - 1) / RXK_WAVES_PER_BLOCK;
-    // a batch of at most half the chip's wavefronts: one workgroup per walker up to the number of compute units, so that the
-    // kernel's first-item rule (a workgroup's wavefront 0 first, see rx_solve_kernel) puts ONE walker on a compute unit before
-    // any unit gets a second one -- walkers that share a unit slow each other down (a rank's block of a strong-scaled ensemble)
-    if (h->small_grid && items <= 2L * h->num_cu) blocks = std::min<long>(items, h->num_cu);
     // one wavefront per SIMD up to ~7 rounds of the chip, then the two-wavefront build: measured crossover between 6144 and 8192
     // walkers with the refinement (scripts/occ_crossover.py, round 5: 6144 walkers 1.64 against 1.78 ms, 8192 walkers 1.88 against
     // 1.73) -- below it a launch is mostly its 200-iteration walkers, which run faster alone on their SIMD.  (Both builds give
@@ -606,7 +601,6 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming)) != hipSuccess) return hipfail("hipEventCreate", e);
     { const char *no = getenv("RX_NO_ORDER"); h->issue_order = (no && *no && *no != '0') ? 0 : 1; }   // read once
-    { const char *sg = getenv("RX_SMALL_GRID"); h->small_grid = (sg && *sg == '0') ? 0 : 1; }         // (A/B of the rule in launch())
     int nb = 0;
     kernel_fn k = kernel_for(h->NL, 2, is_exact(h));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)

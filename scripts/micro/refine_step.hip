@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64, 1) void k_refine(const double *A, const double 
         rf_load_minv<NL>(sM, li < NL ? li : NL - 1, mrow);
         double xx = x;
         asm volatile("" : "+v"(xx));
-        ok = rf_refine<NL, false>(arow, sA, mrow, nb, xx, (1ull << NL) - 1ull, steps);
+        double tot; ok = rf_refine<NL, false>(arow, sA, mrow, nb, xx, (1ull << NL) - 1ull, steps, tot);
         if (r == reps - 1 && isrow) xout[lane] = xx;
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
