@@ -8,6 +8,7 @@ from radex_emcee_amd.engine import Engine
 from radex_emcee_amd import workloads
 N = 1024
 cfg = workloads.config2(N); e = Engine(); e.set_source(cfg["tbg"]); W = cfg["walkers"]; n = 10 ** W[:, 0]
+if os.environ.get("RX_REFINE") == "0": e.set_refinement(False)
 r = e.solve_batch(10 ** W[:, 1], 10 ** W[:, 2], np.stack([0.25 * n, 0.75 * n], 1))
 d = np.fromfile("/tmp/stamps.bin").reshape(-1, 64)[:N]
 slow = np.flatnonzero(np.asarray(r["niter"]) >= 200)

@@ -23,7 +23,8 @@ if not os.environ.get("RX_MARKS_ASM"):
 else:
     d = os.path.dirname(os.environ["RX_MARKS_ASM"])
 lines = open(os.path.join(d, "k.s")).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3rxk15" + kern) and ":" in l.split(";")[0])
+sym = kern if kern.startswith("_ZN") else "_ZN3rxk15" + kern          # (the sampler: --kernel _ZN3rxs17rx_sampler_kernelILi41ELi1ELb1)
+start = next(i for i, l in enumerate(lines) if l.startswith(sym) and ":" in l.split(";")[0])
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 
 
@@ -44,12 +45,15 @@ def cls(op):
 
 
 seg = "before the iteration loop"
+seen = {}
 count = collections.OrderedDict()
 for l in lines[start:end]:
     t = l.strip()
     m = re.match(r";\s*RXMARK (\w+)", t)
     if m:
         seg = m.group(1)
+        seen[seg] = seen.get(seg, 0) + 1
+        if seen[seg] > 1: seg += " #%d" % seen[seg]                   # (a kernel that holds the solve more than once)
         continue
     if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
         continue
