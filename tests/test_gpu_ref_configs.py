@@ -7,8 +7,9 @@ cold start; surface brightness by core.py:986-1003 from the binary's T_ex / tau 
 
 Bars: iteration counts and conv flags equal (a convergence test may flip on the last bit: at most 0.5 % of the walkers, and those
 still within the flux bar); line surface brightness / flux within 1e-4 relative + the background floor of
-tests/test_gpu_parity.py (|dS| <= 1e-4 |S| + 1e-10 max_l backi_l); walkers the binary stops at maxiter (their answer is a
-snapshot of an iteration that never settles) are held to 1e-3."""
+tests/test_gpu_parity.py (|dS| <= 1e-4 |S| + 1e-10 max_l backi_l) -- for the walkers the binary stops at maxiter too (their answer is a
+snapshot of an iteration that never settles: they were held to 1e-3 while the kernels ran an elimination in every iteration;
+observed since round 5's refinement: 1.1e-8 at worst)."""
 import os
 
 import numpy as np
@@ -49,7 +50,7 @@ def _check_solves(tag, r, niter, conv, sb, backi):
     d = np.abs(got - sb)
     both_nan = np.isnan(got) & np.isnan(sb)
     settled = (conv == 1)[:, None]
-    tol = np.where(settled, 1e-4, 1e-3) * np.abs(sb) + floor
+    tol = 1e-4 * np.abs(sb) + floor
     ok = (d <= tol) | both_nan
     assert ok.all(), (tag, np.argwhere(~ok)[:5], (d / tol)[~ok][:5])
     sig = settled & (1e-4 * np.abs(sb) > 100.0 * floor) & np.isfinite(sb)        # (where the background floor plays no part)
@@ -72,8 +73,7 @@ def test_config2_headline_batch_against_the_reference_binary(eng, ref):
     flux, st, nit = eng.model_flux_batch(cfg["walkers"], return_info=True)
     want = ref["c2_sb"][:, cfg["Jup"] - 1] * (10.0 ** cfg["walkers"][:, 3:4]) * 1e23
     floor = 1e-10 * ref["c2_backi"].max(axis=1, keepdims=True) * (10.0 ** cfg["walkers"][:, 3:4]) * 1e23
-    settled = (ref["c2_conv"] == 1)[:, None]
-    tol = np.where(settled, 1e-4, 1e-3) * np.abs(want) + floor
+    tol = 1e-4 * np.abs(want) + floor
     ok = (np.abs(flux - want) <= tol) | (np.isnan(flux) & np.isnan(want))
     assert ok.all(), np.argwhere(~ok)[:5]
 

@@ -89,7 +89,7 @@ def test_config3_sixteen_sources_one_launch(eng, mol):
         assert _rel(lnp[sl][okm], rl[okm]).max() < 1e-6, s["name"]
         mx = fin & (rst == RX_MAXITER)
         if mx.any():
-            assert _rel(lnp[sl][mx], rl[mx]).max() < 5e-4, s["name"]
+            assert _rel(lnp[sl][mx], rl[mx]).max() < 1e-4, s["name"]     # (5e-4 before round 5's refinement; observed since: 1e-8)
         # fluxes of this source's walkers (its own line list) against the oracle
         flux, fst, fnit = eng.model_flux_batch(P[sl], src=s["slot"], return_info=True)
         rf, rfst, _ = O.model_flux_batch(mol, srcs[k], P[sl], nthreads=NTH)
@@ -119,7 +119,7 @@ def test_two_component_issue_order_against_oracle(eng, mol):
     fin = np.isfinite(rl)
     assert np.array_equal(fin, np.isfinite(lnp)) and fin.sum() > 2000
     dok, dmx = _report("2-comp, 4096 walkers, issue order on", lnp, rl, rst)
-    assert dok < 1e-6 and dmx.max() < 5e-4
+    assert dok < 1e-6 and dmx.max() < 1e-4                               # (maxiter tier: 5e-4 before round 5; observed since: 2.2e-8)
     flux = eng.model_flux_batch(W[2040:2300])
     rf = O.model_flux_batch(mol, src, W[2040:2300], nthreads=NTH)[0]
     ok, d = _flux_ok(flux, rf, W[2040:2300], cfg["tbg"], mol, ncomp=2)
@@ -142,13 +142,15 @@ def test_full_width_parity_config5(eng, mol):
     assert np.array_equal(fin, np.isfinite(lnp))
     dok, dmx = _report("config 5, 65536 walkers", lnp, rl, rst)
     assert dok < 1e-4
-    # maxiter tier (observed over 262 144 walkers: worst 1.5e-4, 99.9th percentile 9.5e-7; profiles/r4_big_parity_262144.txt)
-    assert np.percentile(dmx, 99.9) <= 1e-4 and dmx.max() < 1e-3
+    # maxiter tier.  Round 4 (an elimination in every iteration): worst 1.5e-4 over 262 144 walkers, asserted 1e-3.  Since round 5's
+    # refinement: 1.6e-5 here (99.9th percentile 2.7e-6), 2.9e-5 over 262 144 walkers and ONE walker at 1.09e-4 among four more
+    # draws of 131 072 (profiles/r5_big_parity_262144.txt, r5_big_parity_seeds.txt): asserted 3e-4 / 2e-5.
+    assert np.percentile(dmx, 99.9) <= 2e-5 and dmx.max() < 3e-4
     # the fluxes themselves, at the same width (north_star's bar is stated on flux).  Two tiers, as README states
     # them: walkers that converge -- 1e-4 relative (+ the background floor) on every line; walkers that stop at
     # maxiter = 200 never settle and amplify round-off over their 200 iterations (in the reference their answer
     # even depends on the worker's previous walker, emcee/pyradex/core.py:896): 99.9 % of their fluxes within 1e-4,
-    # none beyond 1e-3 (observed worst: 1.6e-5).
+    # none beyond 3e-4 (observed worst since round 5: 7.0e-5, inside the floor-augmented tolerance; 1e-3 asserted before).
     flux, fst, _ = eng.model_flux_batch(cfg["walkers"], return_info=True)
     rflux, rfst, _ = O.model_flux_batch(mol, src, cfg["walkers"], nthreads=NTH)
     assert np.array_equal(fst, rfst)
@@ -165,7 +167,7 @@ def test_full_width_parity_config5(eng, mol):
     print("maxiter walkers: %d, flux entries within tolerance %.5f; relative deviation of all their flux entries: 99th pct %.2e, "
           "99.9th pct %.2e, max %.2e; worst beyond tolerance %.2e"
           % (int(mx.sum()), frac_ok, np.percentile(rel, 99), np.percentile(rel, 99.9), float(rel.max()), float(relw.max())))
-    assert frac_ok >= 0.999 and (ok[mx] | (rel < 1e-3)).all()
+    assert frac_ok >= 0.999 and (ok[mx] | (rel < 3e-4)).all()
 
 
 def test_full_width_parity_config4(eng, mol):
@@ -178,7 +180,7 @@ def test_full_width_parity_config4(eng, mol):
     fin = np.isfinite(rl)
     assert np.array_equal(fin, np.isfinite(lnp)) and fin.sum() > 1000
     dok, dmx = _report("config 4, 2048 two-component walkers", lnp, rl, rst)
-    assert dok < 1e-6 and dmx.max() < 5e-4
+    assert dok < 1e-6 and dmx.max() < 1e-4                               # (maxiter tier: 5e-4 before round 5; observed since: 1.4e-14)
 
 
 def test_device_index_is_validated_not_substituted(co_path, mol):
