@@ -474,6 +474,34 @@ def test_reference_kats_with_a_real_co_dat_on_the_gpu():
     np.testing.assert_almost_equal(RR.tex[0], 37.88, decimal=1)
 
 
+def test_rate_setup_forms_agree_bit_for_bit(co_path, toy_path):
+    """The collisional half of a walker's set-up exists in two forms: with one wavefront per SIMD lane i evaluates the detailed
+    balance of all nlev partners of level i, with two every unordered pair of levels is evaluated once (rx_kernel.hip.inc:
+    PAIRS_ONCE).  Same expression per pair, ctot summed in the same order: the populations, T_ex, tau and iteration counts must
+    be the same bits.  Only the CO ladder instantiation has the second form (the general two-wavefront kernels keep the first:
+    see the comment at PAIRS_ONCE); the general 41-level instantiation (sphere geometry) and the toy molecule (6 levels in the
+    8-level instantiation) are held to the same bar between the two builds."""
+    rng = np.random.default_rng(77)
+    for path, geom, npart in ((co_path, "lvg", 2), (co_path, "sphere", 2), (toy_path, "lvg", 1), (toy_path, "sphere", 1)):
+        e = Engine(path, escapeProbGeom=geom)
+        assert e.npart == npart
+        e.set_source(2.73)
+        N = 3000
+        tkin = 10.0 ** rng.uniform(0.6, 2.9, N)
+        cd = 10.0 ** rng.uniform(12.0, 18.5, N)
+        dens = 10.0 ** rng.uniform(1.5, 6.5, (N, npart))
+        dens[::7, 0] = 0.0 if npart > 1 else dens[::7, 0]              # (a partner without density is skipped)
+        res = []
+        for occ in (1, 2):
+            e.set_waves_per_simd(occ)
+            res.append(e.solve_batch(tkin, cd, dens))
+        e.set_waves_per_simd(0)
+        e.close()
+        assert (res[0]["status"] == RX_OK).sum() > N // 2, (path, geom)
+        for k in ("status", "niter", "xpop", "tex", "tau", "sb"):
+            assert np.array_equal(res[0][k], res[1][k], equal_nan=True), (os.path.basename(path), geom, k)
+
+
 def test_one_and_two_wavefronts_per_simd_agree_bit_for_bit(eng, mol):
     """The "same chain bit for bit across schedules and ranks" claims need the two builds of the solve to give the SAME bits:
     a rank's block is nq / nranks tasks, so a rank can run the one-wavefront-per-SIMD build (its exp / log constants held
