@@ -1,0 +1,26 @@
+"""Stamped build (-DRX_STAMPS -DRX_STAMP_MASK=0x7f8000000000000ull: the set-up slots 51..58 only): where a walker's time goes
+before its first and after its last iteration, medians over the 1024 walkers of the headline batch (cycles of s_memtime).
+usage: python scripts/dbg/stamp_setup.py lib.so"""
+import os, sys
+os.environ["RADEX_EMCEE_AMD_LIB"] = os.path.abspath(sys.argv[1]); os.environ["RX_STAMP_FILE"] = "/tmp/stamps.bin"
+sys.path.insert(0, ".")
+import numpy as np
+from radex_emcee_amd.engine import Engine
+from radex_emcee_amd import workloads
+N = 1024
+cfg = workloads.config2(N); e = Engine(); e.set_source(cfg["tbg"]); W = cfg["walkers"]; n = 10 ** W[:, 0]
+r = e.solve_batch(10 ** W[:, 1], 10 ** W[:, 2], np.stack([0.25 * n, 0.75 * n], 1))
+d = np.fromfile("/tmp/stamps.bin").reshape(-1, 64)[:N]
+names = {56: "kernel: tables staged, item taken", 57: "in front of solve_wave", 51: "rates: start", 52: "rates: table sums done",
+         53: "detailed balance done", 54: "static part of the matrix written", 55: "first iteration starts", 58: "behind solve_wave"}
+order = [56, 57, 51, 52, 53, 54, 55, 58]
+t0 = d[:, 56].min()
+print("earliest walker's slot 56 = 0; medians over %d walkers (cycles), and the step from the previous slot" % N)
+prev = None
+for s in order:
+    v = d[:, s]
+    print("  slot %d %-40s median %9.0f  min %9.0f  max %9.0f   step %s" % (s, names[s], np.median(v - t0), (v - t0).min(), (v - t0).max(),
+          "" if prev is None else "%8.0f" % np.median(v - d[:, prev])))
+    prev = s
+nit = np.asarray(r["niter"])
+print("iterations: median %d; time 55 -> 58 per iteration, median %.0f cycles" % (np.median(nit), np.median((d[:, 58] - d[:, 55]) / nit)))
