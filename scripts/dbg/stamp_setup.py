@@ -1,14 +1,15 @@
 """Stamped build (-DRX_STAMPS -DRX_STAMP_MASK=0x7f8000000000000ull: the set-up slots 51..58 only): where a walker's time goes
 before its first and after its last iteration, medians over the 1024 walkers of the headline batch (cycles of s_memtime).
-usage: python scripts/dbg/stamp_setup.py lib.so"""
+usage: python scripts/dbg/stamp_setup.py lib.so [N=1024: the first N walkers of the batch] [maxiter]"""
 import os, sys
 os.environ["RADEX_EMCEE_AMD_LIB"] = os.path.abspath(sys.argv[1]); os.environ["RX_STAMP_FILE"] = "/tmp/stamps.bin"
 sys.path.insert(0, ".")
 import numpy as np
 from radex_emcee_amd.engine import Engine
 from radex_emcee_amd import workloads
-N = 1024
-cfg = workloads.config2(N); e = Engine(); e.set_source(cfg["tbg"]); W = cfg["walkers"]; n = 10 ** W[:, 0]
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+cfg = workloads.config2(1024); e = Engine(); e.set_source(cfg["tbg"]); W = cfg["walkers"][:N]; n = 10 ** W[:, 0]
+if len(sys.argv) > 3: e.set_iteration_limits(0, int(sys.argv[3]))        # (e.g. 1: set-up + one iteration + epilogue)
 r = e.solve_batch(10 ** W[:, 1], 10 ** W[:, 2], np.stack([0.25 * n, 0.75 * n], 1))
 d = np.fromfile("/tmp/stamps.bin").reshape(-1, 64)[:N]
 names = {56: "kernel: tables staged, item taken", 57: "in front of solve_wave", 51: "rates: start", 52: "rates: table sums done",
@@ -24,3 +25,13 @@ for s in order:
     prev = s
 nit = np.asarray(r["niter"])
 print("iterations: median %d; time 55 -> 58 per iteration, median %.0f cycles" % (np.median(nit), np.median((d[:, 58] - d[:, 55]) / nit)))
+# the clock all XCDs share (s_memrealtime, 100 MHz): kernel entry of the walker's workgroup, its first item taken, its results stored
+rt = d[:, [61, 62, 63]] * 0.01                                   # us
+t00 = rt[:, 0].min()
+print("shared clock, us after the first workgroup entered the kernel: workgroup entry median %.1f max %.1f | item taken (tables staged) median %.1f max %.1f | "
+      "results stored median %.1f max %.1f" % (np.median(rt[:, 0] - t00), (rt[:, 0] - t00).max(), np.median(rt[:, 1] - t00), (rt[:, 1] - t00).max(),
+                                             np.median(rt[:, 2] - t00), (rt[:, 2] - t00).max()))
+print("entry -> item taken: median %.1f us, max %.1f us" % (np.median(rt[:, 1] - rt[:, 0]), (rt[:, 1] - rt[:, 0]).max()))
+print("item taken -> results stored: median %.1f us, min %.1f, max %.1f; cycles 56 -> 58 (s_memtime): median %.0f -> %.2f GHz if that is the shader clock"
+      % (np.median(rt[:, 2] - rt[:, 1]), (rt[:, 2] - rt[:, 1]).min(), (rt[:, 2] - rt[:, 1]).max(), np.median(d[:, 58] - d[:, 56]),
+         np.median(d[:, 58] - d[:, 56]) / np.median(rt[:, 2] - rt[:, 1]) * 1e-3))
