@@ -35,3 +35,9 @@ print("entry -> item taken: median %.1f us, max %.1f us" % (np.median(rt[:, 1] -
 print("item taken -> results stored: median %.1f us, min %.1f, max %.1f; cycles 56 -> 58 (s_memtime): median %.0f -> %.2f GHz if that is the shader clock"
       % (np.median(rt[:, 2] - rt[:, 1]), (rt[:, 2] - rt[:, 1]).min(), (rt[:, 2] - rt[:, 1]).max(), np.median(d[:, 58] - d[:, 56]),
          np.median(d[:, 58] - d[:, 56]) / np.median(rt[:, 2] - rt[:, 1]) * 1e-3))
+# the average clock over a walker's life, by how long it lived
+ghz = (d[:, 58] - d[:, 56]) / (rt[:, 2] - rt[:, 1]) * 1e-3
+for lo, hi in ((0, 20), (20, 30), (30, 50), (50, 100), (100, 199), (200, 201)):
+    m = (nit >= lo) & (nit < hi)
+    if m.any():
+        print("walkers with %3d..%3d iterations: %4d, alive for %6.1f us (median), average clock over that time %.2f GHz" % (lo, hi - 1, m.sum(), np.median((rt[:, 2] - rt[:, 1])[m]), np.median(ghz[m])))
