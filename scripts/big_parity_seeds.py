@@ -1,10 +1,14 @@
+"""GPU against the CPU checker's reference arithmetic on draws of 131 072 prior-box walkers (status, iteration counts, lnprob per tier).
+usage: python scripts/big_parity_seeds.py [--norefine] [seed ...]   (--norefine: every solve the pivoted elimination)"""
 import sys, time; sys.path.insert(0, ".")
 import numpy as np
 from oracle import oracle as O
 from radex_emcee_amd import workloads
 from radex_emcee_amd.engine import Engine
 eng = Engine(); mol = O.Molecule(eng.molfile)
-for seed in (11, 222, 3333, 44444):
+if "--norefine" in sys.argv:
+    sys.argv.remove("--norefine"); eng.set_refinement(False); print("refinement off")
+for seed in ([int(x) for x in sys.argv[1:]] or (11, 222, 3333, 44444)):
     cfg = workloads.config2(131072, seed=seed)
     eng.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
     tf = eng.model_flux_batch(cfg["truth"][None, :])[0]
