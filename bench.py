@@ -311,11 +311,14 @@ def main():
         assert torch.equal(torch.nan_to_num(lnp_all[rank * per:rank * per + nmine], neginf=-1e300),
                            torch.nan_to_num(lnp[:nmine], neginf=-1e300))
 
-    # how the solves of this rank's block were made (rx_refinement_counters): one untimed launch between two resets
+    # how the solves of this rank's block were made (rx_refinement_counters): ONE untimed launch of the counting instantiation of
+    # the solve kernel between two resets (rx_set_refinement_counting; the timed launches do not carry the counters)
+    eng.set_refinement_counting(True)
     eng.refinement_counters(reset=True)
     step()
     torch.cuda.synchronize()
     rfc = eng.refinement_counters(reset=True)
+    eng.set_refinement_counting(False)
     # kernel time from HIP events recorded on the launch stream (inside the library): this rank's block
     kreps = max(5, min(50, args.steps))
     kms = eng.time_lnprob_torch(P, lnp[:nmine], st, nit, reps=kreps, stream=stream) if nmine else 0.0

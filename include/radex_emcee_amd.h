@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 5
+#define RX_ABI_VERSION 6
 #define RX_MAX_SOURCES 64      /* sources resident in one handle (config 3: 16) */
 #define RX_MAX_NJ      32      /* observed lines per source                     */
 #define RX_MAX_LEVELS  64      /* one level per lane of a 64-wide wavefront     */
@@ -160,8 +160,11 @@ int rx_set_waves_per_simd(rx_handle *h, int waves);
  * profiles/r5_refine_gate_*.txt); enabled = 0 -- the pivoted elimination every iteration, as the reference does.  Exists in
  * the CO / LVG instantiation with one wavefront per SIMD; elsewhere every solve is pivoted either way.                     */
 int rx_set_refinement(rx_handle *h, int enabled);
-/* Diagnostics: totals over the 1-component / solve batches evaluated since the last reset -- out5 = iterations, solves made
- * as refinements, corrections made, attempts given up, inverses kept.                                                      */
+/* Diagnostics: totals over the 1-component / solve batches evaluated WHILE COUNTING WAS ON since the last reset -- out5 =
+ * iterations, solves made as refinements, corrections made, attempts given up, inverses kept.  Counting is off by default:
+ * rx_set_refinement_counting(h, 1) makes the following launches use an instantiation of the solve kernel that carries the
+ * counters (the same arithmetic, the same results bit for bit, 2.5 % more time on the 1024-walker launch).                 */
+int rx_set_refinement_counting(rx_handle *h, int enabled);
 int rx_refinement_counters(rx_handle *h, uint64_t *out5, int reset);
 
 /* The caller of lnprob on the device: emcee's StretchMove (a = 2) inside RedBlueMove with two

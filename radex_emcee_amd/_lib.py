@@ -30,9 +30,9 @@ EXPORTS = [
     "rx_sampler_peer_run", "rx_sampler_peer_finish", "rx_sampler_peer_close", "rx_set_sampler_grid_limit",
     "rx_sampler_stats", "rx_lnprior_batch", "rx_set_sampler_speculation", "rx_sampler_spec_stats",
     "rx_sampler_peer_same_device", "rx_set_sampler_stall_ms", "rx_sampler_peer_abort", "rx_peer_topology",
-    "rx_sampler_peer_disconnect", "rx_set_refinement", "rx_refinement_counters",
+    "rx_sampler_peer_disconnect", "rx_set_refinement", "rx_set_refinement_counting", "rx_refinement_counters",
 ]
-ABI_VERSION = 5
+ABI_VERSION = 6
 RX_MAX_RANKS = 8
 RX_IPC_HANDLE_BYTES = 64
 
@@ -108,6 +108,7 @@ def load():
     L.rx_set_issue_order.argtypes = [vp, C.c_int]
     L.rx_set_waves_per_simd.argtypes = [vp, C.c_int]
     L.rx_set_refinement.argtypes = [vp, C.c_int]
+    L.rx_set_refinement_counting.argtypes = [vp, C.c_int]
     L.rx_refinement_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.rx_set_source_prior.argtypes = [vp, C.c_int, C.c_int]
     L.rx_lnprior_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp]

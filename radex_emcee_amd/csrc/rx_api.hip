@@ -235,6 +235,7 @@ struct rx_handle {
     } peer;
     unsigned int *d_order_cnt = nullptr;
     int force_occ = 0;               // 0: choose by batch size; 1 / 2: wavefronts per SIMD (rx_set_waves_per_simd)
+    int rf_count = 0;                // rx_set_refinement_counting: launch the instantiation that adds to d_rf_counters
     int refine = 1;                  // rx_set_refinement: most solves refine a kept solution (rx_refine.hip.inc); 0: every solve pivoted
     unsigned long long *d_rf_counters = nullptr;   // [5] rx_refinement_counters
     float *d_rf_gmem = nullptr;      // the two-wavefront CO kernels' kept inverses: [largest grid x wavefronts][2][rf_minv_floats]
@@ -305,10 +306,12 @@ sampler_kernel_fn sampler_kernel_for(int NL, int occ, bool exact)
 }
 
 // exact = the molecule fills the instantiation (nlev == NL): only built for CO's 41 levels
-kernel_fn kernel_for(int NL, int occ, bool exact)
+kernel_fn kernel_for(int NL, int occ, bool exact, bool count = false)
 {
-    if (NL == 41 && exact)
+    if (NL == 41 && exact) {
+        if (count) return occ >= 2 ? rxk::rx_solve_kernel<41, 2, true, true> : rxk::rx_solve_kernel<41, 1, true, true>;
         return occ >= 2 ? rxk::rx_solve_kernel<41, 2, true> : rxk::rx_solve_kernel<41, 1, true>;
+    }
     switch (NL) {
 #define RX_CASE(n) case n: return occ >= 2 ? rxk::rx_solve_kernel<n, 2, false> : rxk::rx_solve_kernel<n, 1, false>;
         RX_NL_CASES
@@ -508,7 +511,7 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     const long cap = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    kernel_fn k = kernel_for(h->NL, occ, is_exact(h));
+    kernel_fn k = kernel_for(h->NL, occ, is_exact(h), h->rf_count != 0);
     // (every wavefront of the grid takes the item of its own index first, without the queue: the counter starts behind them)
     HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->d_queue, (int)(blocks * RXK_WAVES_PER_BLOCK), 1, st));
     if (e0) HIPCHK(h, hipEventRecord(e0, st));
@@ -595,8 +598,8 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if ((e = hipMemset(h->d_srcs, 0, sizeof(RxSourceDev) * RX_MAX_SOURCES)) != hipSuccess) return hipfail("hipMemset", e);
     if ((e = hipMalloc(&h->d_queue, sizeof(unsigned int))) != hipSuccess) return hipfail("hipMalloc", e);
     if ((e = hipMalloc(&h->d_order_cnt, 2 * RXK_ORDER_BUCKETS * sizeof(unsigned int))) != hipSuccess) return hipfail("hipMalloc", e);
-    if ((e = hipMalloc(&h->d_rf_counters, 5 * sizeof(unsigned long long))) != hipSuccess) return hipfail("hipMalloc", e);
-    if ((e = hipMemset(h->d_rf_counters, 0, 5 * sizeof(unsigned long long))) != hipSuccess) return hipfail("hipMemset", e);
+    if ((e = hipMalloc(&h->d_rf_counters, RXK_RF_SLOTS * RXK_RF_SLOT_WORDS * sizeof(unsigned long long))) != hipSuccess) return hipfail("hipMalloc", e);
+    if ((e = hipMemset(h->d_rf_counters, 0, RXK_RF_SLOTS * RXK_RF_SLOT_WORDS * sizeof(unsigned long long))) != hipSuccess) return hipfail("hipMemset", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return hipfail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming)) != hipSuccess) return hipfail("hipEventCreate", e);
@@ -748,14 +751,24 @@ int rx_set_refinement(rx_handle *h, int enabled)
     return 0;
 }
 
+int rx_set_refinement_counting(rx_handle *h, int enabled)
+{
+    if (!h) return RX_E_ARG;
+    h->rf_count = enabled ? 1 : 0;
+    return 0;
+}
+
 int rx_refinement_counters(rx_handle *h, uint64_t *out5, int reset)
 {
     if (!h || !out5) return RX_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     if (h->in_flight) { HIPCHK(h, hipEventSynchronize(h->ev_done)); h->in_flight = false; }
-    unsigned long long v[5];
+    unsigned long long v[RXK_RF_SLOTS * RXK_RF_SLOT_WORDS];                  // (one slot per cache line: rx_tables.h)
     HIPCHK(h, hipMemcpy(v, h->d_rf_counters, sizeof v, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 5; ++i) out5[i] = v[i];
+    for (int i = 0; i < 5; ++i) {
+        out5[i] = 0;
+        for (int s = 0; s < RXK_RF_SLOTS; ++s) out5[i] += v[s * RXK_RF_SLOT_WORDS + i];
+    }
     if (reset) HIPCHK(h, hipMemset(h->d_rf_counters, 0, sizeof v));
     return 0;
 }

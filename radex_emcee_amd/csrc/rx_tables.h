@@ -16,6 +16,12 @@
 // Per-line constants.  Everything here is a pure function of the molecular
 // data file, evaluated on the host with the same operand order the reference
 // uses at run time, so hoisting it out of the iteration changes no rounding.
+// The refinement's diagnostic counters are spread over RXK_RF_SLOTS cache lines (128 B apart): five atomics per walker on ONE line were
+// 164 k same-address atomics per 32 768-walker launch (a floor of 2 ms for a launch limited to one iteration) and 2.6 % of the
+// 1024-walker headline; rx_refinement_counters sums the slots.
+#define RXK_RF_SLOTS 64
+#define RXK_RF_SLOT_WORDS 16
+
 struct RxLineTab {
     int32_t m[RXK_MAXLINES];        // upper level, 0-based   (iupp-1)
     int32_t n[RXK_MAXLINES];        // lower level, 0-based   (ilow-1)
@@ -93,7 +99,8 @@ struct RxKArgs {
     int32_t refine;                 // != 0: most solves from iteration 12 on refine a kept solution (rx_refine.hip.inc); 0: every solve pivoted
     int32_t pad2_;
     float *rf_gmem;                 // two-wavefronts-per-SIMD CO kernels: [grid wavefronts][2] kept inverses (rx_refine.hip.inc); null: no refinement there
-    unsigned long long *rf_counters;// optional [5]: iterations, solves replaced, corrections, attempts given up, inverses kept (atomics)
+    unsigned long long *rf_counters;// optional [RXK_RF_SLOTS][RXK_RF_SLOT_WORDS], the first 5 words of a slot: iterations, solves replaced,
+                                    // corrections, attempts given up, inverses kept (atomics; a workgroup adds to slot blockIdx.x % RXK_RF_SLOTS)
     double deltav_cms, fortho;
     // RXK_MODE_SOLVE inputs
     const double *tkin, *cdmol, *dens;

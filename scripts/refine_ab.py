@@ -30,9 +30,11 @@ def rel(a, b):
 res = {}
 for on in (False, True):
     eng.set_refinement(on)
+    eng.set_refinement_counting(True)
     eng.refinement_counters(reset=True)
     lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True)
     cnt = eng.refinement_counters(reset=True)
+    eng.set_refinement_counting(False)
     ts = []
     for _ in range(20):
         t = time.perf_counter(); eng.lnprob_batch(cfg["walkers"]); ts.append(time.perf_counter() - t)

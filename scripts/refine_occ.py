@@ -16,7 +16,7 @@ for occ, on in ((2, False), (2, True), (1, False), (1, True)):
     ts = []
     for _ in range(7):
         t = time.perf_counter(); eng.lnprob_batch(cfg["walkers"]); ts.append(time.perf_counter() - t)
-    eng.refinement_counters(reset=True); lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True); c = eng.refinement_counters()
+    eng.set_refinement_counting(True); eng.refinement_counters(reset=True); lnp, st, nit = eng.lnprob_batch(cfg["walkers"], return_info=True); c = eng.refinement_counters(); eng.set_refinement_counting(False)
     import hashlib
     print("32768 walkers, %d wavefront(s) per SIMD, refinement %-3s: %.2f ms per launch (host-timed median); refined %.1f %% of %d iterations; sha1 of lnprob %s"
           % (occ, "on" if on else "off", 1e3 * np.median(ts), 100.0 * c["refined"] / max(c["iterations"], 1), c["iterations"], hashlib.sha1(lnp.tobytes()).hexdigest()[:12]))

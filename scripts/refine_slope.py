@@ -28,7 +28,7 @@ def t_launch(maxiter, on):
 
 for on in (False, True):
     t = {m: t_launch(m, on) for m in (10, 12, 20, 40, 100, 200)}
-    eng.set_iteration_limits(10, 200); eng.refinement_counters(reset=True); eng.lnprob_batch(W); c = eng.refinement_counters()
+    eng.set_iteration_limits(10, 200); eng.set_refinement_counting(True); eng.refinement_counters(reset=True); eng.lnprob_batch(W); c = eng.refinement_counters(); eng.set_refinement_counting(False)
     print("refinement %-3s: launch (us) %s" % ("on" if on else "off", {k: round(v, 1) for k, v in t.items()}))
     print("   per iteration: 10-12 %.2f us | 12-20 %.2f | 20-40 %.2f | 40-100 %.2f | 100-200 %.2f ; counters per walker %s" % (
         (t[12] - t[10]) / 2, (t[20] - t[12]) / 8, (t[40] - t[20]) / 20, (t[100] - t[40]) / 60, (t[200] - t[100]) / 100,

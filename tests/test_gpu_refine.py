@@ -43,6 +43,7 @@ def test_refinement_against_the_pivoted_solve_and_the_checker(eng, mol):
     O.set_refine(0)
     rl, rst, rnit = O.lnprob_batch(mol, src, W, nthreads=16)
     out = {}
+    eng.set_refinement_counting(True)                   # (the instantiation of the solve kernel that feeds the counters)
     for on in (False, True):
         eng.set_refinement(on)
         eng.refinement_counters(reset=True)
@@ -50,6 +51,12 @@ def test_refinement_against_the_pivoted_solve_and_the_checker(eng, mol):
         cnt = eng.refinement_counters(reset=True)
         if not on:
             assert cnt["refined"] == 0 and cnt["kept"] == 0
+    eng.set_refinement_counting(False)
+    # the kernel every other launch uses carries no counters: the same results bit for bit, and nothing is counted
+    plain = eng.lnprob_batch(W, return_info=True)
+    for x, y in zip(plain, out[True]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert eng.refinement_counters(reset=True)["iterations"] == 0
     eng.set_refinement(True)
     (l0, s0, n0), (l1, s1, n1) = out[False], out[True]
     assert np.array_equal(s0, rst) and np.array_equal(s1, rst)
@@ -103,9 +110,11 @@ def test_switched_off_every_solve_is_pivoted_again(eng, mol):
     cfg = workloads.config2(2048, seed=24680)
     src = _source(eng, mol, cfg)
     eng.set_refinement(False)
+    eng.set_refinement_counting(True)
     eng.refinement_counters(reset=True)
     l0, s0, n0 = eng.lnprob_batch(cfg["walkers"], return_info=True)
     cnt = eng.refinement_counters(reset=True)
+    eng.set_refinement_counting(False)
     eng.set_refinement(True)
     assert cnt["refined"] == 0 and cnt["corrections"] == 0 and cnt["kept"] == 0 and cnt["iterations"] == int(n0.sum())
     rl, rst, rnit = O.lnprob_batch(mol, src, cfg["walkers"], nthreads=16)
