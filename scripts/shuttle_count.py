@@ -3,14 +3,14 @@ build: comment markers at the segment boundaries): how much of what a lone wavef
 (v_accvgpr_read / write, v_readlane / v_writelane = SGPR spill traffic, scratch), plain moves and pads, and how much is work.
 Weighted with the measured path mix (refinement counters of the 1024-walker headline) it gives executed counts per iteration.
 
-    python scripts/shuttle_count.py [--kernel 'rx_solve_kernelILi41ELi1ELb1']
+    python scripts/shuttle_count.py [--kernel 'rx_solve_kernelILi41ELi1ELb1ELb0']
 
 Static counts are upper bounds for segments with internal branches (the escape-probability branches of Phase A, the rare
 pivot path of the elimination); the correction loop body is one basic block chain and exact."""
 import collections, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-kern = "rx_solve_kernelILi41ELi1ELb1"
+kern = "rx_solve_kernelILi41ELi1ELb1ELb0"          # (the kernel every launch uses; ...ELb1ELb1: the counting instantiation)
 if "--kernel" in sys.argv:
     kern = sys.argv[sys.argv.index("--kernel") + 1]
 d = tempfile.mkdtemp(prefix="rxmarks")
