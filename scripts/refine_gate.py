@@ -62,11 +62,10 @@ def compare(tag, base, var, cnt):
     return out
 
 
-# k cycles of a lone wavefront per iteration (stamped build): everything but the solve 2.8, the pivoted
-# solve with its hand-over 11.0, the same carrying the inverse ~15.5 (estimate: +21 instructions per elimination step), a
-# refined iteration's fixed part (matrix to registers, the kept inverse out of the AGPRs) ~0.8, a refinement step ~0.75
-# (estimate: 2 x (12 rotations + 33 broadcast FMAs + 30 instructions of cross-group sum) + the test)
-C_REST, C_SOLVE, C_INVERT, C_REFINE, C_STEP = 2.8, 11.0, 15.5, 0.8, 0.75
+# k cycles of a lone wavefront per iteration as stamped on the final kernels of round 5: everything but the solve
+# 2.5 (Phase A 1.2, hand-over 0.1, T_ex 0.8, stop rules 0.4), the pivoted solve 10.9, the same carrying the inverse 15.0, a refined
+# iteration's fixed part (both rows from LDS, first replication, total) 0.85, a correction 0.9
+C_REST, C_SOLVE, C_INVERT, C_REFINE, C_STEP = 2.5, 10.9, 15.0, 0.85, 0.9
 
 
 def cost_model(cnt):
