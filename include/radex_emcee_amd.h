@@ -163,7 +163,9 @@ int rx_set_refinement(rx_handle *h, int enabled);
 /* Diagnostics: totals over the 1-component / solve batches evaluated WHILE COUNTING WAS ON since the last reset -- out5 =
  * iterations, solves made as refinements, corrections made, attempts given up, inverses kept.  Counting is off by default:
  * rx_set_refinement_counting(h, 1) makes the following launches use an instantiation of the solve kernel that carries the
- * counters (the same arithmetic, the same results bit for bit, 2.5 % more time on the 1024-walker launch).                 */
+ * counters (the same arithmetic, the same results bit for bit, 2.8 % more time on the 1024-walker launch: it is the general
+ * instantiation, which also serves a handle whose iteration limits differ from the reference's 10 / 200 or whose refinement
+ * is switched off -- the default state runs a kernel with all of that as compile-time constants).                          */
 int rx_set_refinement_counting(rx_handle *h, int enabled);
 int rx_refinement_counters(rx_handle *h, uint64_t *out5, int reset);
 

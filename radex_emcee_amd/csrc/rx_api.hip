@@ -306,10 +306,10 @@ sampler_kernel_fn sampler_kernel_for(int NL, int occ, bool exact)
 }
 
 // exact = the molecule fills the instantiation (nlev == NL): only built for CO's 41 levels
-kernel_fn kernel_for(int NL, int occ, bool exact, bool count = false)
+kernel_fn kernel_for(int NL, int occ, bool exact, bool general = false)
 {
     if (NL == 41 && exact) {
-        if (count) return occ >= 2 ? rxk::rx_solve_kernel<41, 2, true, true> : rxk::rx_solve_kernel<41, 1, true, true>;
+        if (general) return occ >= 2 ? rxk::rx_solve_kernel<41, 2, true, true> : rxk::rx_solve_kernel<41, 1, true, true>;
         return occ >= 2 ? rxk::rx_solve_kernel<41, 2, true> : rxk::rx_solve_kernel<41, 1, true>;
     }
     switch (NL) {
@@ -511,7 +511,10 @@ int launch(rx_handle *h, RxKArgs &a, hipStream_t st, hipEvent_t e0 = nullptr, hi
     const long cap = (long)h->num_cu * (occ == 2 ? h->blocks_per_cu2 : 1);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    kernel_fn k = kernel_for(h->NL, occ, is_exact(h), h->rf_count != 0);
+    // (a handle in its default state -- the reference's iteration limits, refinement on, no counting -- runs the instantiation that has
+    // those as constants: rx_kernel.hip.inc, GEN)
+    const bool general = h->rf_count != 0 || h->refine == 0 || h->miniter != 10 || h->maxiter != 200;
+    kernel_fn k = kernel_for(h->NL, occ, is_exact(h), general);
     // (every wavefront of the grid takes the item of its own index first, without the queue: the counter starts behind them)
     HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->d_queue, (int)(blocks * RXK_WAVES_PER_BLOCK), 1, st));
     if (e0) HIPCHK(h, hipEventRecord(e0, st));
