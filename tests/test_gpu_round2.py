@@ -480,6 +480,52 @@ def test_reference_kats_with_a_real_co_dat_on_the_gpu():
     np.testing.assert_almost_equal(RR.tex[0], 37.88, decimal=1)
 
 
+def test_iteration_limits_other_than_the_references(co_path, mol):
+    """rx_set_iteration_limits (Radex.run_radex's miniter / maxiter, core.py:460-463, 903-920).  A handle in its default state runs
+    the instantiation of the solve kernel that has 10 / 200 as constants; any other limits select the general one (rx_kernel.hip.inc:
+    GEN).  Explicit 10 / 200 must be the default bit for bit; with maxiter = 60 every walker that needs fewer iterations keeps its
+    bits, every other stops at 60 with RX_MAXITER; and both limits are held to the checker's run_radex on single walkers."""
+    e = Engine(co_path)
+    e.set_source(2.73)
+    rng = np.random.default_rng(5)
+    N = 2000
+    tkin = 10.0 ** rng.uniform(0.7, 2.9, N)
+    cd = 10.0 ** rng.uniform(13.0, 18.8, N)
+    n = 10.0 ** rng.uniform(1.8, 6.2, N)
+    dens = np.stack([0.25 * n, 0.75 * n], 1)
+    base = e.solve_batch(tkin, cd, dens)
+    e.set_iteration_limits(10, 200)
+    same = e.solve_batch(tkin, cd, dens)
+    for k in ("status", "niter", "xpop", "tex", "tau"):
+        assert np.array_equal(base[k], same[k], equal_nan=True), k
+    e.set_iteration_limits(10, 60)
+    cut = e.solve_batch(tkin, cd, dens)
+    short = base["niter"] < 60
+    assert short.sum() > N // 2 and (~short).sum() > 20
+    for k in ("status", "niter", "xpop", "tex", "tau"):
+        assert np.array_equal(base[k][short], cut[k][short], equal_nan=True), k
+    assert (cut["niter"][~short] == 60).all()
+    stopped = ~short & (base["niter"] > 60)
+    assert (cut["status"][stopped] == RX_MAXITER).all()
+    e.set_iteration_limits(25, 200)                      # (miniter only gates the python-side stop rule, core.py:911-920: matrix_'s own
+    late = e.solve_batch(tkin, cd, dens)                 #  convergence test ends the loop from iteration 10 on whatever it is)
+    assert (late["niter"] >= base["niter"]).all()
+    # the checker, walker by walker, with the same limits
+    for lim, got in (((10, 60), cut), ((25, 200), late)):
+        for w in list(np.flatnonzero(~short)[:6]) + list(np.flatnonzero(short)[:6]):
+            st = O.State(mol)
+            st.backrad(2.73)
+            st.set_density({2: dens[w, 0], 3: dens[w, 1]})
+            st.s.tkin = tkin[w]; st.s.cdmol = cd[w]
+            assert st.rates() == 0
+            it, conv = st.run(False, lim[0], lim[1])
+            assert abs(int(got["niter"][w]) - it) <= 0 or base["niter"][w] >= 200, (lim, w, got["niter"][w], it)
+            x = st.arr("xpop").copy()
+            assert np.max(np.abs(got["xpop"][w] - x) / np.maximum(np.abs(x), 1e-10)) < 1e-6 or it >= lim[1], (lim, w)     # (populations below 1e-10 of the total are round-off)
+    e.set_iteration_limits(10, 200)
+    e.close()
+
+
 def test_rate_setup_forms_agree_bit_for_bit(co_path, toy_path):
     """The collisional half of a walker's set-up exists in two forms: with one wavefront per SIMD lane i evaluates the detailed
     balance of all nlev partners of level i, with two every unordered pair of levels is evaluated once (rx_kernel.hip.inc:
