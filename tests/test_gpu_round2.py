@@ -480,6 +480,30 @@ def test_reference_kats_with_a_real_co_dat_on_the_gpu():
     np.testing.assert_almost_equal(RR.tex[0], 37.88, decimal=1)
 
 
+def test_ortho_fraction_of_h2(co_path):
+    """rx_set_fortho: the share of n_H2 that goes to oH2 (default 0.75 = opr / (1 + opr), emcee_radex.py:95-96, 124-126).  The
+    fluxes of model_lvg with another share must be those of the solve with the densities split by hand."""
+    e = Engine(co_path)
+    cfg = workloads.config2(512, seed=77)
+    e.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
+    W = cfg["walkers"]
+    n = 10.0 ** W[:, 0]
+    for f in (0.75, 0.6, 0.0):
+        e.set_fortho(f)
+        flux, st, nit = e.model_flux_batch(W, return_info=True)
+        r = e.solve_batch(10.0 ** W[:, 1], 10.0 ** W[:, 2], np.stack([(1.0 - f) * n, f * n], 1))
+        want = r["sb"][:, np.asarray(cfg["Jup"]) - 1] * (10.0 ** W[:, 3:4]) * 1e23
+        assert np.array_equal(st, r["status"])
+        ok = (st == RX_OK)
+        assert ok.sum() > 400 and (nit[ok] == r["niter"][ok]).mean() > 0.99
+        # (the split is formed on the device as n (1 - f), n f: the last bit of a density may differ from the host's product, and a
+        # line much fainter than the walker's brightest is the difference of two nearly equal terms)
+        tol = 1e-6 * np.abs(want) + 1e-9 * np.nanmax(np.abs(want), axis=1, keepdims=True)
+        assert (np.abs(flux - want)[ok] <= tol[ok]).all(), (f, float(np.nanmax((np.abs(flux - want) / tol)[ok])))
+    e.set_fortho(0.75)
+    e.close()
+
+
 def test_iteration_limits_other_than_the_references(co_path, mol):
     """rx_set_iteration_limits (Radex.run_radex's miniter / maxiter, core.py:460-463, 903-920).  A handle in its default state runs
     the instantiation of the solve kernel that has 10 / 200 as constants; any other limits select the general one (rx_kernel.hip.inc:
