@@ -231,6 +231,23 @@ class Engine:
                   "rx_lnprob_batch_device")
         return lnp, status, niter
 
+    def model_flux_batch_torch(self, params, src=0, flux=None, status=None, niter=None, stream=None):
+        """model_lvg on device buffers (rx_model_flux_batch_device): params a CUDA float64 tensor [N, 4*ncomp(src)]; returns
+        flux [N, nJ(src)], status, niter as CUDA tensors; asynchronous on `stream`."""
+        import torch
+        assert params.is_cuda and params.dtype == torch.float64 and params.is_contiguous() and params.dim() == 2
+        N = params.shape[0]
+        dev = params.device
+        if flux is None:
+            flux = torch.empty((N, self._sources[int(src)]["nJ"]), dtype=torch.float64, device=dev)
+        if status is None:
+            status = torch.empty(N, dtype=torch.int32, device=dev)
+        if niter is None:
+            niter = torch.empty(N, dtype=torch.int32, device=dev)
+        self._chk(self._L.rx_model_flux_batch_device(self._h, int(src), N, params.data_ptr(), flux.data_ptr(), status.data_ptr(),
+                                                     niter.data_ptr(), self._stream(dev, stream)), "rx_model_flux_batch_device")
+        return flux, status, niter
+
     def time_lnprob_torch(self, params, lnp, status, niter, reps=10, src_index=None, stream=None):
         """Mean per-launch kernel time [ms] from HIP events recorded on the launch stream."""
         ms = C.c_double(0.0)

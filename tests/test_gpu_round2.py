@@ -480,6 +480,20 @@ def test_reference_kats_with_a_real_co_dat_on_the_gpu():
     np.testing.assert_almost_equal(RR.tex[0], 37.88, decimal=1)
 
 
+def test_model_flux_on_device_buffers(eng):
+    """rx_model_flux_batch_device (device pointers, a caller's stream) gives what rx_model_flux_batch gives through host buffers."""
+    import torch
+    cfg = workloads.config2(700, seed=3)
+    eng.set_source(cfg["tbg"], cfg["Jup"], np.ones(10), np.ones(10), cfg["bounds"])
+    f0, s0, n0 = eng.model_flux_batch(cfg["walkers"], return_info=True)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        P = torch.from_numpy(cfg["walkers"]).cuda()
+        f1, s1, n1 = eng.model_flux_batch_torch(P, stream=st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(f0, f1.cpu().numpy(), equal_nan=True) and np.array_equal(s0, s1.cpu().numpy()) and np.array_equal(n0, n1.cpu().numpy())
+
+
 def test_ortho_fraction_of_h2(co_path):
     """rx_set_fortho: the share of n_H2 that goes to oH2 (default 0.75 = opr / (1 + opr), emcee_radex.py:95-96, 124-126).  The
     fluxes of model_lvg with another share must be those of the solve with the densities split by hand."""
