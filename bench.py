@@ -538,7 +538,21 @@ def main():
                     if rank == 0:
                         rec["multi_gpu_halfsteps_allgather"]["same_final_state_as_one_gpu"] = bool(sha3 == sha1_one)
                     del smp
-                    best = rec["multi_gpu_dataflow"] if d2 <= d3 else rec["multi_gpu_halfsteps_allgather"]
+                    # (4) what a user gets WITHOUT naming a schedule: "auto" -- rank 0 alone + one broadcast by rule for ensembles
+                    # in one GPU's latency regime, a timed probe of the candidates otherwise (the probe is the first call: untimed)
+                    smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp)
+                    d4, sha4 = timed_run(smp, c["walkers"], nst)
+                    d4 = max_over_ranks(d4)
+                    rec["auto"] = entry(d4, "auto -> %s" % smp.last_schedule,
+                                        {"rank0": "one broadcast of the state per run_mcmc call", "halfsteps": "all_gather_into_tensor per half-step",
+                                         "dataflow-peer": "none on the data path; two host barriers per run_mcmc call"}.get(smp.last_schedule, "?"), d1)
+                    rec["auto"].update({"chosen": smp.schedule_choice, "why": smp.schedule_reason, "probe": smp.auto_probe,
+                                        "ranks_share_one_gpu": bool(share)})
+                    if rank == 0:
+                        rec["auto"]["same_final_state_as_one_gpu"] = bool(sha4 == sha1_one)
+                    pre["schedules"][name]["auto"] = {"chosen": smp.schedule_choice, "why": smp.schedule_reason}
+                    del smp
+                    best = min((rec["auto"], rec["multi_gpu_dataflow"], rec["multi_gpu_halfsteps_allgather"]), key=lambda e: e["ms_per_step"])
                 else:
                     best = rec["one_gpu_dataflow"]
                 # the line of this shape: the best schedule at this N, next to the one-GPU dataflow number

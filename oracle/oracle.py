@@ -107,6 +107,7 @@ def lib():
                                       C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.rxo_set_refine.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.rxo_set_refine_componentwise.argtypes = [C.c_double, C.c_double, C.c_double]
         L.rxo_refine_counters.argtypes = [C.POINTER(C.c_long)] * 5 + [C.c_int]
         _lib = L
     return _lib
@@ -117,6 +118,11 @@ def set_refine(first_iter=0, tol=1e-10, max_steps=4, lag=2, crit=0, d1max=0.0, l
     state created afterwards -- the scheme of the device kernels, restated on the CPU so that it can be
     measured against the reference's arithmetic (radex_oracle.h: rxo_set_refine)."""
     lib().rxo_set_refine(int(first_iter), float(tol), int(max_steps), int(lag), int(crit), float(d1max), float(loose), int(backoff))
+
+
+def set_refine_componentwise(rel, floor, loose_rel):
+    """Thresholds of set_refine(crit=2): per level, relative to its population in the start vector."""
+    lib().rxo_set_refine_componentwise(float(rel), float(floor), float(loose_rel))
 
 
 def refine_counters(reset=True):

@@ -44,6 +44,7 @@ static const double FK_PY  = 1.4387768775039338;
  *      OFF unless rxo_set_refine was called: see radex_oracle.h) -------------------------------- */
 static int    RF_FIRST = 0, RF_MAXSTEPS = 4, RF_LAG = 2, RF_CRIT = 0, RF_BACKOFF = 0;
 static double RF_TOL = 1e-10, RF_D1MAX = 0.0, RF_LOOSE = 0.0;
+static double RF_CW_REL = 0.0, RF_CW_FLOOR = 0.0, RF_CW_LOOSE = 0.0;   /* crit 2: componentwise acceptance (rxo_set_refine_componentwise) */
 static long   RF_CNT[5];            /* full solves, refined solves, refinement steps, failed attempts, inverses kept */
 
 void rxo_set_refine(int first_iter, double tol, int max_steps, int lag, int crit, double d1max, double loose, int backoff)
@@ -51,6 +52,11 @@ void rxo_set_refine(int first_iter, double tol, int max_steps, int lag, int crit
     RF_FIRST = first_iter; RF_TOL = tol; RF_MAXSTEPS = max_steps;
     RF_LAG = (lag == 1) ? 1 : 2; RF_CRIT = crit; RF_D1MAX = d1max;
     RF_LOOSE = loose; RF_BACKOFF = backoff;
+}
+
+void rxo_set_refine_componentwise(double rel, double floor, double loose_rel)
+{
+    RF_CW_REL = rel; RF_CW_FLOOR = floor; RF_CW_LOOSE = loose_rel;
 }
 
 void rxo_refine_counters(long *full, long *refined, long *steps, long *failed, long *kept, int reset)
@@ -510,20 +516,35 @@ static int rf_solve(rxo_state *s, int niter)
             const double loose = RF_LOOSE > 0.0 ? RF_LOOSE * 0.125 : 0.0;
             int big = 0, big1 = 0, bigl = 0;
             for (int i = 0; i < n; i++) {
-                if (!(fabs(d[i]) < thr)) big = 1;
+                double thr_i = thr, loose_i = loose;
+                if (RF_CRIT == 2) {
+                    /* componentwise: a level's correction is measured against that level's own population in the start vector
+                     * (floored near minpop, below which matrix_ clamps anyway): small populations keep their RELATIVE accuracy */
+                    const double sc = fmax(fabs(s->rf_x[p][i]), RF_CW_FLOOR);
+                    thr_i = fmin(thr, RF_CW_REL * sc);
+                    loose_i = fmin(loose, RF_CW_LOOSE * sc);
+                    const int32_t q = rf_hi(d[i]) - rf_hi(thr_i);         /* log2(|d_i| / thr_i) in units of 2^-20 */
+                    if (i == 0 || q > hd) hd = q;
+                }
+                if (!(fabs(d[i]) < thr_i)) big = 1;
                 if (!(fabs(d[i]) < thr1)) big1 = 1;
-                if (!(fabs(d[i]) < loose)) bigl = 1;
+                if (!(fabs(d[i]) < loose_i)) bigl = 1;
             }
             if (!big) { ok = 1; break; }
             if (!bigl && !lprev) { ok = 1; break; }
             lprev = bigl;
-            if (getenv("RXO_RF_TRACE")) fprintf(stderr, "RF %d %d %.3e %.3e\n", niter, st, dmax / xmax0, st ? dmax / dprev : 0.0);
+            if (getenv("RXO_RF_TRACE")) {
+                double rmax = 0.0; int imax = -1;
+                for (int i = 0; i < n; i++) { double q = fabs(d[i]) / fmax(fabs(xx[i]), 1e-20); if (q > rmax) { rmax = q; imax = i; } }
+                fprintf(stderr, "RF %d %d %.3e %.3e | rel %.3e at level %d (x %.3e)\n", niter, st, dmax / xmax0, st ? dmax / dprev : 0.0, rmax, imax, xx[imax]);
+            }
             dprev = dmax;
             if (st == 0) { if (big1) break; continue; }
             if (st < 3 || ((st - 3) & 1)) continue;
-            if (hd >= 0x7ff00000) break;                                   /* inf / NaN */
+            if (RF_CRIT != 2 && hd >= 0x7ff00000) break;                   /* inf / NaN */
+            if (RF_CRIT == 2 && !(dmax < INFINITY)) break;
             if (st > 3) {
-                const int32_t D2 = hprev - hd, G = hd - rf_hi(thr);
+                const int32_t D2 = hprev - hd, G = (RF_CRIT == 2) ? hd : hd - rf_hi(thr);
                 if (D2 <= 0 || (long long)(RF_MAXSTEPS - 1 - st) * D2 < 2ll * (G > 0 ? G : 1)) break;
             }
             hprev = hd;

@@ -90,6 +90,9 @@ typedef struct rxo_state {
  *                residuals resolve for an ill-conditioned system (0: no such rule);
  *   backoff    : from the second failed attempt in a row on, pause the attempts for 2, 4, ... 64 iterations.      */
 void rxo_set_refine(int first_iter, double tol, int max_steps, int lag, int crit, double d1max, double loose, int backoff);
+/* crit 2 of rxo_set_refine: thresholds per component, thr_i = min(tol / 8, rel * max(|x_kept_i|, floor)), the same for
+ * `loose` with loose_rel; the rate rule works on max_i log2(|d_i| / thr_i). */
+void rxo_set_refine_componentwise(double rel, double floor, double loose_rel);
 void rxo_refine_counters(long *full, long *refined, long *steps, long *failed, long *kept, int reset);
 
 rxo_mol *rxo_mol_load(const char *path, char *err, size_t errlen);

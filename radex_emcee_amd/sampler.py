@@ -415,9 +415,9 @@ class DeviceEnsembleSampler:
               "halfsteps": one propose / solve / accept round per half-step
     group     torch.distributed group, one process per GPU: the proposals of every half-step are dealt out
               in contiguous blocks, one per rank (the reference's Pool.map over walkers,
-              emcee_radex.py:480-488).  The DEFAULT with a group is "halfsteps": block evaluation per rank,
-              ONE all_gather of log-probabilities (RCCL on GPUs) before the accept step -- north_star's and
-              SURVEY 8e's literal form.  schedule="dataflow" with a group is opt-in: every rank runs its
+              emcee_radex.py:480-488).  The DEFAULT with a group is "auto" (below).  "halfsteps": block
+              evaluation per rank, ONE all_gather of log-probabilities (RCCL on GPUs) before the accept step --
+              north_star's and SURVEY 8e's literal form.  schedule="dataflow" with a group: every rank runs its
               block's tasks in its own persistent kernel and publishes each result into the replicas of ALL
               ranks with peer writes over xGMI (rx_sampler_peer_*: IPC-mapped fine-grained memory, no
               collective, no barrier per half-step, no host in the loop).  That path has only ever run with
@@ -428,7 +428,22 @@ class DeviceEnsembleSampler:
               "halfsteps" from then on.  It also falls back when the replicas cannot be shared (IPC
               unavailable) or a run is abandoned (watchdog).  Positions and the counter-based random stream
               are replicated either way, so the proposals need no exchange and every rank accepts
-              identically.  The chain is the one-GPU chain, bit for bit, under both schedules."""
+              identically.  The chain is the one-GPU chain, bit for bit, under every schedule.
+              "rank0": the ensemble is too small to shard -- rank 0 advances it alone with the one-GPU schedule
+              (the dataflow kernel on a GPU) and ONE broadcast per run_mcmc call hands positions,
+              log-probabilities, acceptance counts and the stored chain to the other ranks.
+              "auto" (the default with a group) never lets the group lose to one GPU: with at most
+              AUTO_RANK0_TASKS proposals per half-step (one GPU's latency regime: a half-step lasts as long as its
+              slowest walker wherever it runs, and sharding only adds a collective to it) it is "rank0" by rule;
+              above that the first run_mcmc call times `verify_peer_steps` steps of each candidate -- "rank0",
+              "halfsteps" and, when the replicas connect and its chain verifies, the peer-write dataflow -- from the
+              same state (which is restored: the random stream is counter based) and keeps the fastest by the
+              slowest rank's clock.  Every rank takes the same decision (the timings are gathered; the choice is
+              a function of the gathered list).  `schedule_choice`, `schedule_reason` and `auto_probe` say what was
+              chosen and why [/root/reference/emcee/emcee_radex.py:480-488: the pool never makes a run slower
+              than processes=1 by more than its IPC]."""
+
+    AUTO_RANK0_TASKS = 1536     # proposals per half-step up to which one GPU runs one wavefront per SIMD (rx_api.hip: 6 x 256 CUs)
 
     def __init__(self, nwalkers, ndim, engine=None, log_prob_fn=None, nens=1, ens_src=None, a=2.0, seed=0,
                  group=None, sharded=None, schedule=None, verify_peer_steps=8):
@@ -478,10 +493,16 @@ class DeviceEnsembleSampler:
         # schedule (single GPU, engine backend): "dataflow" = one persistent kernel, every proposal starts
         # as soon as the two walkers it reads are final (rx_sampler_run_async_device); "halfsteps" = propose /
         # solve / accept launches per half-step (rx_sampler_run_device).  The chains are bit-identical.
-        if schedule is None:              # the peer-write path across GPUs is opt-in (see the class docstring)
-            schedule = "halfsteps" if self._sharded else "dataflow"
-        if schedule not in ("dataflow", "halfsteps"):
-            raise ValueError("schedule must be 'dataflow' or 'halfsteps'")
+        if schedule is None:              # with a group: never slower than one GPU (see the class docstring)
+            schedule = "auto" if self._sharded else "dataflow"
+        if schedule not in ("dataflow", "halfsteps", "auto", "rank0"):
+            raise ValueError("schedule must be 'dataflow', 'halfsteps', 'auto' or 'rank0'")
+        if schedule in ("auto", "rank0") and not self._sharded:
+            schedule = "dataflow"         # one process: nothing to choose
+        self.requested_schedule = schedule
+        self.schedule_choice = None       # "auto": what the rule or the probe chose ("rank0", "halfsteps", "dataflow-peer")
+        self.auto_probe = None            # "auto": seconds per candidate over verify_peer_steps steps (the slowest rank's)
+        self.broadcast_chain = True       # "rank0": the stored chain goes to every rank (emcee's API on every rank)
         self.schedule = schedule
         self.verify_peer_steps = int(verify_peer_steps)
         self.peer_verified = None         # None: not checked (yet); True / False: the first peer run against the half-step schedule
@@ -751,6 +772,109 @@ class DeviceEnsembleSampler:
                                                % [i for i, r in enumerate(res) if not r[1]] if not all(r[1] for r in res) else "differed")}
         return self.peer_verified
 
+    # --- "rank0": the ensemble on one GPU, one broadcast per call -----------------------------------------
+    def _bcast(self, t):
+        if self.world == 1 or t is None:
+            return
+        if t.is_cuda and self._dist.get_backend(self.group) == "gloo":     # (rehearsals: ranks that share one GPU)
+            h = t.cpu()
+            self._dist.broadcast(h, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            t.copy_(h)
+        else:
+            self._dist.broadcast(t, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+
+    def _unsharded(self, nsteps, chain, chain_lnp):
+        """nsteps steps on THIS rank alone, with the schedule a sampler without a group uses."""
+        if self.engine is not None and not self.time_solves:
+            self.engine.sampler_run_async_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed,
+                                                self.step_counter, nsteps, self.coords, self.lnp, self.naccept,
+                                                chain, chain_lnp, ens_src=self.ens_src)
+            self.engine.sampler_wait(self.coords.device)
+        elif self.engine is not None:
+            self.last_solve_ms = self.engine.sampler_run_torch(
+                self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed, self.step_counter, nsteps,
+                self.coords, self.lnp, self.naccept, chain, chain_lnp, ens_src=self.ens_src, time_solves=True)
+        else:
+            sharded, self._sharded = self._sharded, False
+            try:
+                self._halfsteps(nsteps, chain, chain_lnp)
+            finally:
+                self._sharded = sharded
+
+    def _run_rank0(self, nsteps, chain, chain_lnp, broadcast=True):
+        """One run_mcmc call under "rank0".  An error on rank 0 is raised on EVERY rank."""
+        from .engine import EngineError
+        err = None
+        if self.rank == 0:
+            try:
+                self._unsharded(nsteps, chain, chain_lnp)
+            except EngineError as exc:
+                err = "rank-0 run: %s" % exc
+        bad = self._agree(err)
+        if bad:
+            raise EngineError("sampler (schedule rank0), rank %d: %s" % bad[0])
+        if broadcast:
+            for t in (self.coords, self.lnp, self.naccept) + ((chain, chain_lnp) if self.broadcast_chain else ()):
+                self._bcast(t)
+
+    def _timed(self, fn, k):
+        """Seconds this rank needs for k steps of fn from the present state, which is restored."""
+        import time
+        import torch
+        start = (self.coords.clone(), self.lnp.clone(), self.naccept.clone())
+        self._barrier()
+        if self.coords.is_cuda:
+            torch.cuda.synchronize(self.coords.device)
+        t0 = time.perf_counter()
+        ok = fn(k)
+        if self.coords.is_cuda:
+            torch.cuda.synchronize(self.coords.device)
+        self._barrier()
+        dt = time.perf_counter() - t0
+        for dst, src in zip((self.coords, self.lnp, self.naccept), start):
+            dst.copy_(src)
+        return dt if ok is not False else float("inf")
+
+    def _choose(self, nsteps):
+        """"auto", collective, once per sampler: the rule, or the timed probe (class docstring).  Sets schedule_choice."""
+        import torch
+        tasks = self.nq
+        if tasks <= self.AUTO_RANK0_TASKS or self.world == 1:
+            self.schedule_choice = "rank0"
+            self.schedule_reason = ("auto, by rule: %d proposals per half-step <= %d (one GPU's latency regime: sharding adds a "
+                                    "collective per half-step and removes nothing)" % (tasks, self.AUTO_RANK0_TASKS))
+            return
+        k = max(self.verify_peer_steps, 1)
+        cand = {}
+        # the peer-write schedule is a candidate only where the replicas connect AND its chain verifies
+        peer = (self.engine is not None and not self.time_solves
+                and (self.peer_state is True or (self.peer_state is None and self._peer_setup())))
+        if peer and self.peer_verified is None and self.verify_peer_steps > 0:
+            if not self._verify_peer():
+                self.peer_state = "the verification of the peer-write chain against the half-step chain over the first %d steps: %s" % (
+                    self.verify_peer_steps, self.peer_verify_detail["outcome"])
+                self._peer_teardown()
+                peer = False
+        # (one untimed pass first: code objects, RCCL channels and IPC mappings come into being on first use)
+        for timed in (False, True):
+            t = {"halfsteps": self._timed(lambda n: self._halfsteps(n, None, None), k),
+                 "rank0": self._timed(lambda n: self._run_rank0(n, None, None), k)}
+            if peer:
+                t["dataflow-peer"] = self._timed(lambda n: self._run_peer(n, None, None), k)
+            cand = t
+        # the slowest rank's clock decides, identically everywhere
+        allt = self._gather_objects(cand)
+        worst = {name: max(float(r.get(name, float("inf"))) for r in allt) for name in cand}
+        # (ties and near-ties go to the schedule with the least machinery: rank0, then halfsteps)
+        order = sorted(worst, key=lambda n: (worst[n] * (1.0 if n == "rank0" else 1.03 if n == "halfsteps" else 1.06)))
+        self.schedule_choice = order[0]
+        self.auto_probe = {"steps": k, "seconds": worst, "peer_candidate": bool(peer),
+                           "peer_state": None if self.peer_state in (None, True) else str(self.peer_state)}
+        self.schedule_reason = "auto, by probe over %d steps: %s" % (k, ", ".join("%s %.3g ms/step" % (n, 1e3 * worst[n] / k) for n in order))
+        if self.schedule_choice != "dataflow-peer" and peer:
+            self._peer_teardown()
+            self.peer_state = None
+
     # --- sampling ---------------------------------------------------------------------------------------
     def run_mcmc(self, initial_state, nsteps, progress=False, store=True):
         import torch
@@ -777,6 +901,22 @@ class DeviceEnsembleSampler:
         chain = chain_lnp = None
         if self.peer_state is True and getattr(self.engine, "_peer_owner", None) is not self:
             self.peer_state = None        # the handle's replica block now belongs to another sampler: set up again
+        if self._sharded and self.requested_schedule in ("auto", "rank0") and nsteps > 0:
+            if self.requested_schedule == "rank0":
+                self.schedule_choice = "rank0"
+            elif self.schedule_choice is None:
+                self._choose(nsteps)
+            auto_reason = self.schedule_reason if self.requested_schedule == "auto" else "requested"
+            if self.schedule_choice == "rank0":
+                if store:
+                    chain = torch.zeros(nsteps, self.N, self.ndim, dtype=torch.float64, device=self.coords.device)
+                    chain_lnp = torch.zeros(nsteps, self.N, dtype=torch.float64, device=self.coords.device)
+                self._run_rank0(nsteps, chain, chain_lnp)
+                self.last_schedule, self.schedule_reason = "rank0", auto_reason
+                return self._finish_run(nsteps, chain, chain_lnp)
+            self.schedule = "dataflow" if self.schedule_choice == "dataflow-peer" else "halfsteps"
+        else:
+            auto_reason = None
         peer = (self.engine is not None and self._sharded and self.schedule == "dataflow" and not self.time_solves
                 and nsteps > 0 and (self.peer_state is True or (self.peer_state is None and self._peer_setup())))
         if store and nsteps > 0:
@@ -851,6 +991,11 @@ class DeviceEnsembleSampler:
             self._halfsteps(nsteps, chain, chain_lnp)
         if self.schedule_reason is None:
             self.schedule_reason = "requested"
+        if auto_reason is not None and self.schedule_reason.startswith("requested"):
+            self.schedule_reason = auto_reason
+        return self._finish_run(nsteps, chain, chain_lnp)
+
+    def _finish_run(self, nsteps, chain, chain_lnp):
         self.step_counter += nsteps
         self.iteration += nsteps
         if chain is not None:

@@ -118,6 +118,17 @@ def test_bench_gpus_2_starts_its_own_ranks_on_a_shared_gpu():
         # the same seed and start under all three schedules: the final states are the one-GPU run's, bit for bit
         assert m["same_final_state_as_one_gpu"] is True and sh["multi_gpu_halfsteps_allgather"]["same_final_state_as_one_gpu"] is True
         assert sh["multi_gpu_halfsteps_allgather"]["speedup_vs_1gpu"] > 0
+        # the DEFAULT with a group, schedule="auto": the one-GPU chain bit for bit; ensembles in one GPU's latency regime go to
+        # rank 0 alone by rule and cost what one GPU costs (the bar is loose: 12-60 steps on a box that also runs the other rank)
+        au = sh["auto"]
+        assert au["same_final_state_as_one_gpu"] is True and au["chosen"] in ("rank0", "halfsteps", "dataflow-peer")
+        assert pre["schedules"][name]["auto"]["chosen"] == au["chosen"]
+        if name in ("config2", "config4"):
+            assert au["chosen"] == "rank0" and "by rule" in au["why"], au
+            assert au["speedup_vs_1gpu"] > 0.8, au
+        else:
+            assert "by probe" in au["why"] and set(au["probe"]["seconds"]) >= {"rank0", "halfsteps"}, au
+            assert sh["ms_per_step"] <= min(au["ms_per_step"], sh["multi_gpu_halfsteps_allgather"]["ms_per_step"]) + 1e-9
 
 
 def test_bench_collectives_over_rccl_with_a_one_rank_group():

@@ -155,7 +155,11 @@ def test_peer_dataflow_one_rank_group(co_path, mol):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
-        assert DeviceEnsembleSampler(256, 4, engine=e, seed=9, group=dist.group.WORLD).schedule == "halfsteps"   # the default with a group
+        da = DeviceEnsembleSampler(256, 4, engine=e, seed=9, group=dist.group.WORLD)
+        assert da.schedule == "auto"                                # the default with a group
+        st_a = da.run_mcmc(p0, 6)                                   # 128 proposals per half-step: rank 0 alone, by rule
+        assert da.last_schedule == "rank0" and da.schedule_choice == "rank0" and "by rule" in da.schedule_reason
+        assert np.array_equal(st_a.coords, st_ref.coords) and np.array_equal(da.get_chain(), ref.get_chain())
         d = DeviceEnsembleSampler(256, 4, engine=e, seed=9, group=dist.group.WORLD, schedule="dataflow")
         st = d.run_mcmc(p0, 6)
         assert d.last_schedule == "dataflow-peer" and d.peer_state is True

@@ -203,15 +203,39 @@ def lp(P):
     return -0.5 * np.sum((P - mu) ** 2, axis=1)
 # the code path bench.py --gpus N times: replicated state, block-sharded proposals, one all_gather per
 # half-step, identical accept on every rank -- here with the numpy restatement of the kernels
-d = DeviceEnsembleSampler(26, 4, log_prob_fn=lp, seed=123, group=dist.group.WORLD)   # 13 proposals: ragged 7 + 6
+d = DeviceEnsembleSampler(26, 4, log_prob_fn=lp, seed=123, group=dist.group.WORLD, schedule="halfsteps")   # 13 proposals: ragged 7 + 6
 p0 = mu + 1e-3 * np.random.RandomState(0).randn(26, 4)
 lnp0 = -0.5 * np.sum((p0 - mu) ** 2, axis=1)
 from radex_emcee_amd.sampler import State
 st = d.run_mcmc(State(p0, lnp0), 25)
 np.save(sys.argv[5] + "/dcoords_%d.npy" % rank, st.coords)
 np.save(sys.argv[5] + "/dcalls_%d.npy" % rank, np.array(calls))
-# with a group the default schedule is half-steps + all_gather (the peer-write dataflow path across GPUs is opt-in)
 assert d.schedule == "halfsteps" and d.last_schedule == "halfsteps" and d.schedule_reason == "requested"
+ncalls_half = len(calls)
+# with a group the DEFAULT is "auto": 13 proposals per half-step are far below one GPU's latency regime, so by rule rank 0
+# advances the ensemble alone and ONE broadcast per run_mcmc call hands the result to the others
+da = DeviceEnsembleSampler(26, 4, log_prob_fn=lp, seed=123, group=dist.group.WORLD)
+assert da.schedule == "auto"
+sta = da.run_mcmc(State(p0, lnp0), 25)
+assert da.last_schedule == "rank0" and da.schedule_choice == "rank0" and "by rule" in da.schedule_reason, da.schedule_reason
+assert np.array_equal(sta.coords, st.coords) and np.array_equal(da.get_chain(), d.get_chain())      # the same chain, every rank
+assert np.array_equal(da.get_log_prob(), d.get_log_prob()) and np.array_equal(da.acceptance_fraction, d.acceptance_fraction)
+assert len(calls) - ncalls_half == (50 if rank == 0 else 0)       # only rank 0 evaluated anything: 50 half-steps of 13
+assert set(calls[ncalls_half:]) <= {13}
+stb = da.run_mcmc(sta, 5); stc = d.run_mcmc(st, 5)                  # resuming: still the same chain
+assert np.array_equal(stb.coords, stc.coords) and np.array_equal(stb.log_prob, stc.log_prob)
+# above the rule's threshold the candidates are TIMED and every rank takes the same decision
+db = DeviceEnsembleSampler(26, 4, log_prob_fn=lp, seed=123, group=dist.group.WORLD, verify_peer_steps=2)
+db.AUTO_RANK0_TASKS = 4
+std = db.run_mcmc(State(p0, lnp0), 25)
+assert db.schedule_choice in ("rank0", "halfsteps") and "by probe" in db.schedule_reason, db.schedule_reason
+assert set(db.auto_probe["seconds"]) == {"rank0", "halfsteps"} and db.auto_probe["peer_candidate"] is False
+choices = [None, None]
+dist.all_gather_object(choices, (db.schedule_choice, db.last_schedule))
+assert choices[0] == choices[1], choices
+assert np.array_equal(std.coords, st.coords) and np.array_equal(db.get_chain(), d.get_chain()[:25])
+np.save(sys.argv[5] + "/dauto_%d.npy" % rank, sta.coords)
+del calls[ncalls_half:]
 # the collective that replaces the bare barriers of the peer protocol: one rank's failure is seen by EVERY rank
 assert d._agree(None) == []
 bad = d._agree("boom on rank 1" if rank == 1 else None)
@@ -247,3 +271,5 @@ def test_device_sampler_sharded_two_ranks_gloo(tmp_path):
     assert np.array_equal(st.coords, c0)                    # sharded == unsharded, bit for bit
     k0, k1 = np.load(tmp_path / "dcalls_0.npy"), np.load(tmp_path / "dcalls_1.npy")
     assert set(k0) == {7} and set(k1) == {6} and len(k0) == 50
+    # schedule="auto" (rank 0 alone + one broadcast): the unsharded chain on BOTH ranks, bit for bit
+    assert np.array_equal(np.load(tmp_path / "dauto_0.npy"), c0) and np.array_equal(np.load(tmp_path / "dauto_1.npy"), c0)
