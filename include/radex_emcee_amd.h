@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 6
+#define RX_ABI_VERSION 7
 #define RX_MAX_SOURCES 64      /* sources resident in one handle (config 3: 16) */
 #define RX_MAX_NJ      32      /* observed lines per source                     */
 #define RX_MAX_LEVELS  64      /* one level per lane of a 64-wide wavefront     */
@@ -89,6 +89,11 @@ int rx_partner_ids(const rx_handle *h, int32_t *out);
  * spfreq [GHz] (Radex.frequency), 1-based upper/lower level indices.        */
 int rx_line_data(const rx_handle *h, double *xnu, double *spfreq,
                  int32_t *iupp, int32_t *ilow);
+/* The background of a source slot as the kernels hold it -- backrad_'s outputs [radex.so@0x1be30, via the
+ * `tbg` setter emcee/pyradex/core.py:845-854; SURVEY A.1]: backi[rx_nline] = thc xnu^3 / (exp(fk xnu / tbg) - 1)
+ * (1e-30f where fk xnu / tbg >= 160), which is also totalb; trj = tbg for every line (*tbg_out).  The table is
+ * copied back FROM THE DEVICE (what rx_set_source uploaded), not recomputed.  RX_E_STATE when the slot is not set. */
+int rx_background(rx_handle *h, int src, double *backi, double *tbg_out);
 
 /* Ortho fraction used to split n_H2 into oH2/pH2 densities; default 0.75 =
  * opr/(1+opr) with opr = 3 (emcee/emcee_radex.py:95-96).                    */
@@ -156,9 +161,17 @@ int rx_set_waves_per_simd(rx_handle *h, int waves);
 /* How matrix_'s linear solve [radex.so matrix_ -> lubksb_, SURVEY.md A.4 step 4, A.5] is made from iteration 12 of a
  * walker on: enabled = 1 (default) -- as a refinement of the solution of two iterations back against a kept inverse,
  * accepted when the correction is below 2^-43 of a population vector that sums to 1, with the pivoted elimination as the
- * fall-back (its effect on status / iteration counts / fluxes against the reference's arithmetic:
- * profiles/r5_refine_gate_*.txt); enabled = 0 -- the pivoted elimination every iteration, as the reference does.  Exists in
- * the CO / LVG instantiation with one wavefront per SIMD; elsewhere every solve is pivoted either way.                     */
+ * fall-back; enabled = 0 -- the pivoted elimination every iteration, as the reference does.  Exists in
+ * the CO / LVG instantiations (one AND two wavefronts per SIMD); elsewhere every solve is pivoted either way.
+ * What it changes, measured against the reference's arithmetic (profiles/r5_refine_gate_*.txt, r5_big_parity_seeds*.txt,
+ * r6_small_population_gpu.txt): the iteration count of about 1 walker in 10^4 flips by one; lnprob of converged walkers moves by
+ * up to 2e-6 relative; walkers that stop at maxiter (chaotic iterations) move by up to 1.2e-3 (9.8e-4 with it off); level
+ * populations above 1e-6 by up to 5e-8 relative (1e-8 with it off).  Populations BELOW ~1e-11 differ from the reference's by
+ * more than 1e-4 relative WITH OR WITHOUT it (same figures either way: the absolute deviation stays below 1e-14): that is the
+ * rounding error of any double-precision solve of this system, the reference's own LINPACK solve included -- against the exact
+ * solution of its own system it is off by 4e-4 at 1e-12, 5 % at 1e-14 and by factors below 1e-17
+ * (profiles/r6_small_population_accuracy.txt) -- so T_ex and tau of lines between such levels, and fluxes under the
+ * background floor, carry no digits in the reference either.                                                               */
 int rx_set_refinement(rx_handle *h, int enabled);
 /* Diagnostics: totals over the 1-component / solve batches evaluated WHILE COUNTING WAS ON since the last reset -- out5 =
  * iterations, solves made as refinements, corrections made, attempts given up, inverses kept.  Counting is off by default:

@@ -32,7 +32,7 @@ static const double RELAX_NEW = 0.30000001192092896;  /* [BIN 0x26c30] 0.3f   */
 static const double RELAX_OLD = 0.699999988079071;    /* [BIN 0x26c38] 0.7f   */
 static const double EXPGUARD = 160.0;                 /* [BIN 0x26bd0]        */
 static const double SEED_D = 1e-30;                   /* [BIN 0x26bb8]        */
-static const double SEED_F = 1.0000000031710769e-30;  /* [BIN 0x26c40] 1e-30f */
+/* ([BIN 0x26c40] 1e-30f = 1.0000000031710769e-30 only enters rhs / row nplus of matrix_, which the patched lubksb_ ignores) */
 static const double THICK_D = 0.01;                   /* [BIN 0x26c18]        */
 static const double THICK_F = 0.009999999776482582;   /* [BIN 0x26b78] 0.01f  */
 static const double FAT     = 1e5;                    /* [BIN 0x26bc0]        */
@@ -323,7 +323,7 @@ void rxo_backrad(rxo_state *s, double tbg)
     for (int l = 0; l < m->nline; l++) {
         double x = m->xnu[l];
         double h = FK * x / tbg;
-        if (h >= EXPGUARD) s->backi[l] = SEED_F;
+        if (h >= EXPGUARD) s->backi[l] = SEED_D;                     /* the DOUBLE 1e-30 [BIN 0x26bb8]: pinned by ref_backrad_guard.json */
         else s->backi[l] = THC * pow(x, 3.0) / (exp(h) - 1.0);   /* xnu**3. -> pow [BIN 0x1c04f] */
         s->trj[l] = tbg;
         s->totalb[l] = s->backi[l];

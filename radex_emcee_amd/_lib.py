@@ -30,9 +30,9 @@ EXPORTS = [
     "rx_sampler_peer_run", "rx_sampler_peer_finish", "rx_sampler_peer_close", "rx_set_sampler_grid_limit",
     "rx_sampler_stats", "rx_lnprior_batch", "rx_set_sampler_speculation", "rx_sampler_spec_stats",
     "rx_sampler_peer_same_device", "rx_set_sampler_stall_ms", "rx_sampler_peer_abort", "rx_peer_topology",
-    "rx_sampler_peer_disconnect", "rx_set_refinement", "rx_set_refinement_counting", "rx_refinement_counters",
+    "rx_sampler_peer_disconnect", "rx_set_refinement", "rx_set_refinement_counting", "rx_refinement_counters", "rx_background",
 ]
-ABI_VERSION = 6
+ABI_VERSION = 7
 RX_MAX_RANKS = 8
 RX_IPC_HANDLE_BYTES = 64
 
@@ -43,7 +43,7 @@ class EngineLibraryMissing(ImportError):
 
 def build(fast: bool = False, force: bool = False) -> str:
     """Compile the HIP extension in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("rx_api.hip", "rx_kernel.hip.inc", "rx_sampler.hip.inc", "rx_tables.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("rx_api.hip", "rx_kernel.hip.inc", "rx_refine.hip.inc", "rx_sampler.hip.inc", "rx_tables.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "radex_emcee_amd.h"))
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))
@@ -100,6 +100,7 @@ def load():
         f.argtypes = [vp]
     L.rx_partner_ids.argtypes = [vp, ip]
     L.rx_line_data.argtypes = [vp, dp, dp, ip, ip]
+    L.rx_background.argtypes = [vp, C.c_int, dp, dp]
     L.rx_set_fortho.argtypes = [vp, C.c_double]
     L.rx_set_iteration_limits.argtypes = [vp, C.c_int, C.c_int]
     L.rx_set_source.argtypes = [vp, C.c_int, C.c_double, C.c_int, ip, dp, dp, dp, C.c_int, C.c_double]

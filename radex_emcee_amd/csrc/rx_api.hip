@@ -31,7 +31,6 @@ namespace {
 constexpr double H_FK = 1.4387809925261357;
 constexpr double H_THC = 3.972907393443411e-16;
 constexpr double H_FGAUS = 26.753802360251857;
-constexpr double H_SEED_F = 1.0000000031710769e-30;
 // astropy CODATA-2018, emcee/pyradex/core.py:981-984
 constexpr double H_THC_PY = 3.9728917142978573e-16;
 constexpr double H_FK_PY = 1.4387768775039338;
@@ -297,7 +296,8 @@ sampler_kernel_fn sampler_kernel_for(int NL, int occ, bool exact)
     if (NL == 41 && exact)
         return occ >= 2 ? rxs::rx_sampler_kernel<41, 2, true> : rxs::rx_sampler_kernel<41, 1, true>;
     switch (NL) {
-#define RX_CASE(n) case n: return occ >= 2 ? rxs::rx_sampler_kernel<n, 2, false> : rxs::rx_sampler_kernel<n, 1, false>;
+#define RX_CASE(n) case n: if constexpr (rxk::occ2_compiled(n)) { if (occ >= 2) return rxs::rx_sampler_kernel<n < 42 ? n : 8, 2, false>; } \
+                   return rxs::rx_sampler_kernel<n, 1, false>;
         RX_NL_CASES
 #undef RX_CASE
     }
@@ -313,7 +313,8 @@ kernel_fn kernel_for(int NL, int occ, bool exact, bool general = false)
         return occ >= 2 ? rxk::rx_solve_kernel<41, 2, true> : rxk::rx_solve_kernel<41, 1, true>;
     }
     switch (NL) {
-#define RX_CASE(n) case n: return occ >= 2 ? rxk::rx_solve_kernel<n, 2, false> : rxk::rx_solve_kernel<n, 1, false>;
+#define RX_CASE(n) case n: if constexpr (rxk::occ2_compiled(n)) { if (occ >= 2) return rxk::rx_solve_kernel<n < 42 ? n : 8, 2, false>; } \
+                   return rxk::rx_solve_kernel<n, 1, false>;
         RX_NL_CASES
 #undef RX_CASE
     }
@@ -609,7 +610,8 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     { const char *no = getenv("RX_NO_ORDER"); h->issue_order = (no && *no && *no != '0') ? 0 : 1; }   // read once
     int nb = 0;
     kernel_fn k = kernel_for(h->NL, 2, is_exact(h));
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
+    if (rxk::occ2_compiled(h->NL)    // (42-64 levels: no two-wavefront kernels, kernel_for hands out the one-wavefront one)
+        && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, 64 * RXK_WAVES_PER_BLOCK, 0) == hipSuccess && nb > 0)
         h->blocks_per_cu2 = std::min(nb, 2);
     if (rxk::refine_compiled(h->NL, is_exact(h), 2) && h->blocks_per_cu2 >= 2) {
         // (no launch of a two-wavefront kernel has more workgroups than this: launch(), rx_sampler_run_async_device, peer_launch_shape)
@@ -678,6 +680,18 @@ int rx_line_data(const rx_handle *h, double *xnu, double *spfreq, int32_t *iupp,
     return 0;
 }
 
+int rx_background(rx_handle *h, int src, double *backi, double *tbg_out)
+{
+    if (!h) return RX_E_ARG;
+    if (src < 0 || src >= RX_MAX_SOURCES || !h->h_srcs[src].set) { h->err = "source slot not set"; return RX_E_STATE; }
+    RxSourceDev S;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(&S, h->d_srcs + src, sizeof S, hipMemcpyDeviceToHost));
+    for (int l = 0; l < h->mol.nline && backi; ++l) backi[l] = S.backi[l];
+    if (tbg_out) *tbg_out = S.tbg;
+    return 0;
+}
+
 int rx_set_fortho(rx_handle *h, double fortho)
 {
     if (!h || !(fortho >= 0.0 && fortho <= 1.0)) return RX_E_ARG;
@@ -719,7 +733,7 @@ int rx_set_source(rx_handle *h, int src, double tbg, int nJ, const int32_t *Jup,
     for (int l = 0; l < h->mol.nline; ++l) {
         const double x = h->mol.xnu[l];
         const double hh = H_FK * x / tbg;
-        S.backi[l] = (hh >= 160.0) ? H_SEED_F : H_THC * pow(x, 3.0) / (exp(hh) - 1.0);
+        S.backi[l] = (hh >= 160.0) ? 1e-30 : H_THC * pow(x, 3.0) / (exp(hh) - 1.0);   // (the double 1e-30 [BIN 0x26bb8], not 1e-30f: ref_backrad_guard.json)
     }
     HIPCHK(h, hipSetDevice(h->device));
     // the table is read by kernels that may still be running on a non-blocking stream: wait for them

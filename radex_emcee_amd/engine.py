@@ -114,6 +114,14 @@ class Engine:
         self._chk(rc, "rx_set_source")
         self._sources[int(src)] = dict(nJ=len(Jup), ncomp=int(ncomp))
 
+    def background(self, src=0):
+        """backrad_'s outputs for a source slot as the kernels hold them (rx_background): (backi[nline] = totalb, trj = tbg)
+        [/root/reference/emcee/pyradex/core.py:845-854]."""
+        backi = np.zeros(self.nline)
+        tbg = C.c_double(0.0)
+        self._chk(self._L.rx_background(self._h, int(src), _dp(backi), C.byref(tbg)), "rx_background")
+        return backi, tbg.value
+
     def set_source_prior(self, src=0, enabled=True):
         """enabled=False: lnprob_batch returns the log-likelihood alone for this slot (rx_set_source_prior)."""
         self._chk(self._L.rx_set_source_prior(self._h, int(src), 1 if enabled else 0), "rx_set_source_prior")

@@ -88,8 +88,11 @@ def main():
         if nit >= 200 or len(h) < 3:
             continue
         (A2, x2), _, (A0, x_ref) = h
-        x_rf, steps, ok = refine(A0, A2, x2)
-        if not ok:
+        try:
+            x_rf, steps, ok = refine(A0, A2, x2)
+        except np.linalg.LinAlgError:                       # (a NaN / singular system: the maser branch)
+            continue
+        if not ok or not np.all(np.isfinite(x_ref)):
             refused += 1
             continue
         used += 1

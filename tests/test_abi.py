@@ -30,7 +30,7 @@ def test_header_and_export_list_agree():
 def test_library_exports_every_declared_symbol(lib):
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rx_abi_version() == 6
+    assert lib.rx_abi_version() == 7
 
 
 def test_header_cites_reference_interfaces():

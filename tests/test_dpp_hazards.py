@@ -21,10 +21,22 @@ def asm_path(tmp_path_factory):
     d = tmp_path_factory.mktemp("rxasm")
     src = os.path.join(ROOT, "radex_emcee_amd", "csrc", "rx_api.hip")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
-           "-mllvm", "-pragma-unroll-threshold=4000000", "-mllvm", "-disable-machine-licm", "-save-temps", "-c",
-           "-o", "/dev/null", src]
-    subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
+           "-mllvm", "-pragma-unroll-threshold=4000000", "-mllvm", "-disable-machine-licm", "-save-temps",
+           "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src]
+    with open(d / "build.log", "w") as log:              # (warnings and the resource-usage remarks: test 4 reads them)
+        subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=log, timeout=1500)
     return str(d / "rx_api-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def test_every_instantiation_reaches_the_occupancy_it_is_launched_for(asm_path):
+    """4. rx_solve_kernel<NL, OCC, ...> / rx_sampler_kernel<NL, OCC, ...> are launched OCC wavefronts per SIMD (rx_api.hip:
+    kernel_for): the build must not say `desired occupancy was 2, final occupancy is 1`, and the registers must allow OCC
+    (round 5 carried four NL = 48 / 64 instantiations that could never run two per SIMD; they are no longer built)."""
+    log = os.path.join(os.path.dirname(asm_path), "build.log")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "resource_usage.py"), "--check", log],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 finding(s)" in r.stdout.strip().splitlines()[-1], r.stdout[-2000:]
 
 
 def test_no_dpp_read_after_write_hazard(asm_path):

@@ -59,6 +59,30 @@ def test_lubksb_vs_reference_binary(engines, golden_dir):
         assert np.max(np.abs(x - want) / np.abs(want)) < 1e-10, n
 
 
+def test_backrad_vs_reference_binary(engines, golden_dir):
+    """Row a7 on the product side [radex.so@0x1be30 backrad_, through the `tbg` setter emcee/pyradex/core.py:845-854]: the
+    background table rx_set_source uploads -- read back from the DEVICE by rx_background -- equals the reference binary's
+    backi / totalb / trj for all 26 (molecule, T_bg) vectors of ref_backrad.json, bit for bit (host arithmetic in the
+    binary's operand order on the same libm: pow(xnu, 3.0), the 160 guard and its 1e-30 floor)."""
+    g = json.load(open(os.path.join(golden_dir, "ref_backrad.json")))
+    guard = json.load(open(os.path.join(golden_dir, "ref_backrad_guard.json")))     # T_bg 0.24 .. 2 K: the exp-guard branch
+    toy = Engine(os.path.join(golden_dir, "toy6.dat"))
+    assert len(g["cases"]) == 26
+    floor_seen = False
+    for k, c in enumerate(g["cases"] + guard["cases"]):
+        eng = engines[2] if c["mol"] == "co_synth" else toy
+        slot = k % 5                                                   # (slots are independent tables)
+        eng.set_source(c["tbg"], src=slot)
+        backi, trj = eng.background(slot)
+        assert np.array_equal(backi, np.array(c["backi"])), (c["mol"], c["tbg"])
+        assert np.array_equal(backi, np.array(c["totalb"]))            # totalb = backi on this path (SURVEY A.1)
+        assert np.all(np.array(c["trj"]) == trj) and trj == c["tbg"]
+        floor_seen |= bool(np.any(backi == 1e-30))
+    assert floor_seen                                                  # the exp-guard branch is among the vectors
+    with pytest.raises(Exception):
+        toy.background(63)                                             # a slot that was never set
+
+
 def test_lamda_tables_vs_reference_readdata(engines, golden_dir):
     """Row a6 on the product side: what the library's own LAMDA parser (rx_create) holds for the two committed
     files equals what the reference binary's readdata_ parsed from them (ref_readdata.json: xnu = E_up - E_low,

@@ -119,3 +119,51 @@ def test_switched_off_every_solve_is_pivoted_again(eng, mol):
     assert cnt["refined"] == 0 and cnt["corrections"] == 0 and cnt["kept"] == 0 and cnt["iterations"] == int(n0.sum())
     rl, rst, rnit = O.lnprob_batch(mol, src, cfg["walkers"], nthreads=16)
     assert np.array_equal(s0, rst) and (n0 != rnit).sum() <= 2
+
+
+def test_every_level_population_componentwise_with_the_refinement_on(co_path, mol):
+    """xpop, T_ex and tau of rx_solve_batch against the reference's arithmetic COMPONENTWISE, all 41 levels, with the refinement on
+    -- no floor at 1e-10 of the total as in round 5's tests.  The bound is 1e-6 relative + 1e-14 ABSOLUTE per level: the absolute
+    term is what a double-precision solve of this system is worth (the reference's own LINPACK solution is off from the exact
+    solution of its matrix by 4e-4 at a population of 1e-12, by 5 % at 1e-14: profiles/r6_small_population_accuracy.txt), and
+    the device's deviation from the reference's numbers is the same with the refinement on and off
+    (profiles/r6_small_population_gpu.txt: largest absolute deviation 1.2e-14 either way).  T_ex / tau: lines whose two levels
+    both hold more than 1e-9 of the molecules."""
+    e = Engine(co_path)
+    rng = np.random.default_rng(2468)
+    cfg = workloads.config2(1024, seed=1234)                       # the bench headline's walkers ...
+    W = cfg["walkers"]
+    sets = [(cfg["tbg"], 10.0 ** W[:, 1], 10.0 ** W[:, 2], np.stack([0.25 * 10.0 ** W[:, 0], 0.75 * 10.0 ** W[:, 0]], axis=1)),
+            # ... and the wide box of the routine tests against a 2.73 K background (populations down to the 1e-20 clamp)
+            (2.73, 10.0 ** rng.uniform(0.6, 2.9, 1024), 10.0 ** rng.uniform(12.0, 18.5, 1024), 10.0 ** rng.uniform(1.5, 6.5, (1024, 2)))]
+    worst = dict(x=0.0, tex=0.0, tau=0.0, onoff=0.0)
+    small_seen = 0
+    for tbg, tkin, cd, dens in sets:
+        e.set_source(tbg)
+        e.set_refinement(True)
+        on = e.solve_batch(tkin, cd, dens)
+        e.set_refinement(False)
+        off = e.solve_batch(tkin, cd, dens)
+        e.set_refinement(True)
+        ncmp = 0
+        for w in range(len(tkin)):
+            r = O.solve_state(mol, tbg, {2: dens[w, 0], 3: dens[w, 1]}, tkin[w], cd[w])
+            if r["niter"] >= 200 or r["niter"] != on["niter"][w] or not np.all(np.isfinite(r["xpop"])):
+                continue
+            ncmp += 1
+            x = r["xpop"]
+            small_seen += int((x < 1e-13).sum())
+            for got, key in ((on, "x"), (off, "onoff")):
+                q = np.abs(got["xpop"][w] - x) / (1e-6 * x + 1e-14)
+                worst[key] = max(worst[key], q.max())
+                assert q.max() < 1.0, (key, w, int(q.argmax()), x[q.argmax()], got["xpop"][w][q.argmax()])
+            both = np.minimum(x[e.iupp - 1], x[e.ilow - 1]) > 1e-9
+            dt = np.abs(on["tex"][w][both] - r["tex"][both]) / np.abs(r["tex"][both])
+            dta = np.abs(on["tau"][w][both] - r["tau"][both]) / np.abs(r["tau"][both])
+            worst["tex"], worst["tau"] = max(worst["tex"], dt.max()), max(worst["tau"], dta.max())
+            assert dt.max() < 1e-5 and dta.max() < 1e-6, (w, dt.max(), dta.max())
+        assert ncmp > 900
+    assert small_seen > 10000                                       # the small populations are what this test is about
+    print("componentwise, in units of (1e-6 x + 1e-14): refinement on %.2f, off %.2f; T_ex %.1e, tau %.1e (levels > 1e-9)"
+          % (worst["x"], worst["onoff"], worst["tex"], worst["tau"]))
+    e.close()

@@ -557,9 +557,15 @@ def test_iteration_limits_other_than_the_references(co_path, mol):
             st.s.tkin = tkin[w]; st.s.cdmol = cd[w]
             assert st.rates() == 0
             it, conv = st.run(False, lim[0], lim[1])
-            assert abs(int(got["niter"][w]) - it) <= 0 or base["niter"][w] >= 200, (lim, w, got["niter"][w], it)
+            assert int(got["niter"][w]) == it, (lim, w, got["niter"][w], it)          # (cut walkers: exactly the new limit, both sides)
             x = st.arr("xpop").copy()
-            assert np.max(np.abs(got["xpop"][w] - x) / np.maximum(np.abs(x), 1e-10)) < 1e-6 or it >= lim[1], (lim, w)     # (populations below 1e-10 of the total are round-off)
+            # per level 1e-6 relative + 1e-14 absolute (what a double-precision solve resolves: tests/test_gpu_refine.py); a walker
+            # cut at the new maxiter is mid-flight, not chaotic yet -- held to 1e-4 relative + the same floor
+            # (a walker that runs into the REFERENCE's maxiter = 200 is one of the chaotic ones: the maxiter tier of _report)
+            if it >= 200:
+                continue
+            tol = (1e-4 if it >= lim[1] else 1e-6) * np.abs(x) + 1e-14
+            assert np.all(np.abs(got["xpop"][w] - x) <= tol), (lim, w, it, np.max(np.abs(got["xpop"][w] - x) / tol))
     e.set_iteration_limits(10, 200)
     e.close()
 
