@@ -152,7 +152,7 @@ class _FortranIO:
         unit = self._i32(dt + 4).value
         flags = self._u32(dt)
         try:
-            with open(name, "r", newline="") as f:
+            with open(name, "r", newline="", encoding="latin-1") as f:      # (bytes, as a Fortran unit sees them)
                 recs = f.read().split("\n")
         except OSError:
             flags.value = (flags.value & ~3) | 1                      # IOPARM_LIBRETURN_ERROR: the routine's own err= path
@@ -245,6 +245,10 @@ class _FortranIO:
     def transfer_real(self, dt, p, kind):
         tok = self._token(self.stmt[dt])
         t = tok.lower().replace("d", "e")
+        # (libgfortran's read_real also takes an exponent introduced by its sign alone: 1.0-11 = 1.0e-11)
+        k = max(t.rfind("+"), t.rfind("-"))
+        if k > 0 and "e" not in t and t[k - 1] in "0123456789.":
+            t = t[:k] + "e" + t[k:]
         try:
             if kind != 8 or "*" in t or not t or t.strip("+-.0123456789e") or "inf" in t or "nan" in t:
                 raise ValueError(t)
@@ -394,6 +398,13 @@ class RefRadex:
                 os.write(2, ("macho_ref: fatal import %s called\n" % name).encode())
                 os._exit(97)
             return 0
+        if name == "_gfortran_stop_string":                      # STOP 'text': (const char *, int) -- keep the text
+            def stop(msg, n):
+                self.stop_message = C.string_at(msg, n).decode("latin-1") if msg and n > 0 else ""
+                return trap()
+            cb = C.CFUNCTYPE(C.c_long, C.c_void_p, C.c_int)(stop)
+            self._keep.append(cb)
+            return C.cast(cb, C.c_void_p).value
         cb = C.CFUNCTYPE(C.c_long)(trap)
         self._keep.append(cb)
         return C.cast(cb, C.c_void_p).value

@@ -170,6 +170,18 @@ class Molecule:
         self.spfreq = np.ctypeslib.as_array(m.spfreq, (m.nline,)).copy()
         self.xnu = np.ctypeslib.as_array(m.xnu, (m.nline,)).copy()
         self.part_id = [m.part_id[i] for i in range(m.npart)]
+        self.eup = np.ctypeslib.as_array(m.eup, (m.nline,)).copy()
+        self.amass = m.amass
+
+    def partner_tables(self):
+        """[(id, temps[ntemp], lcu[ncoll], lcl[ncoll], coll[ncoll, ntemp])] as parsed (rows naming levels above nlev dropped)"""
+        m, out = self.ptr.contents, []
+        for i in range(m.npart):
+            nc, nt = m.ncoll[i], m.ntemp[i]
+            as_a = lambda p, n: np.ctypeslib.as_array(p, (n,)).copy() if n else np.zeros(0)
+            out.append((m.part_id[i], as_a(m.temp[i], nt), as_a(m.lcu[i], nc), as_a(m.lcl[i], nc),
+                        as_a(m.coll[i], nc * nt).reshape(nc, nt)))
+        return out
 
     def __del__(self):
         try:

@@ -79,113 +79,201 @@ static void set_err(char *err, size_t n, const char *msg)
 /* SURVEY App. A.2.  Records are read strictly in file order, comment lines  */
 /* are consumed positionally exactly as RADEX does (it never looks at '!').  */
 /* ======================================================================== */
-static char *rd_line(FILE *f, char *buf, int n)
+/* One Fortran unit read list-directed, as far as LAMDA files use the form (what the reference binary does with ~100 well- and
+ * ill-formed files is recorded in tests/golden/ref_lamda_corpus.json, make_ref_lamda_corpus.py): a READ starts on a new record,
+ * items are separated by blanks / tabs and at most one comma, a READ whose record runs out goes on in the next one, the rest of
+ * its last record is skipped, a READ without items skips one record; end of file is an error.  Integers are sign + digits;
+ * reals take e / E / d / D or a bare sign as the exponent mark; repeat counts, null values, slashes and quoted strings are
+ * errors here (not implemented).                                                                                      */
+typedef struct { FILE *f; char *rec; size_t cap, len, col; int fresh, bad; } rd_unit;
+
+static int rd_record(rd_unit *u)
 {
-    if (!fgets(buf, n, f)) return NULL;
-    return buf;
+    int c = fgetc(u->f);
+    u->len = u->col = 0;
+    if (c == EOF) { u->bad = 1; return 0; }
+    for (; c != EOF && c != '\n'; c = fgetc(u->f)) {
+        if (u->len + 2 > u->cap) { u->cap = u->cap ? 2 * u->cap : 256; u->rec = (char *)realloc(u->rec, u->cap); }
+        u->rec[u->len++] = (char)c;
+    }
+    if (u->len && u->rec[u->len - 1] == '\r') u->len--;
+    if (u->rec) u->rec[u->len] = 0;
+    return 1;
 }
 
-/* Fortran list-directed reals accept D exponents */
-static double rd_real(char **pp, int *ok)
+static void rd_begin(rd_unit *u) { u->fresh = 1; }
+static void rd_end(rd_unit *u) { if (u->fresh && !u->bad) rd_record(u); u->fresh = 1; }
+static void rd_skip(rd_unit *u) { rd_begin(u); rd_end(u); }
+
+/* the next item of the READ in progress: [*b, *e) inside u->rec; 0 on error */
+static int rd_item(rd_unit *u, size_t *b, size_t *e)
 {
-    char *p = *pp, tmp[64];
-    while (*p && (isspace((unsigned char)*p) || *p == ',')) p++;
-    int k = 0;
-    while (*p && !isspace((unsigned char)*p) && *p != ',' && k < 63) {
-        char c = *p++;
-        tmp[k++] = (c == 'd' || c == 'D') ? 'e' : c;
+    if (u->bad) return 0;
+    if (u->fresh) { if (!rd_record(u)) return 0; u->fresh = 0; }
+    for (;;) {
+        while (u->col < u->len && (u->rec[u->col] == ' ' || u->rec[u->col] == '\t')) u->col++;
+        if (u->col < u->len) break;
+        if (!rd_record(u)) return 0;
     }
-    tmp[k] = 0;
-    *pp = p;
-    if (!k) { *ok = 0; return 0.0; }
+    char c = u->rec[u->col];
+    if (c == ',' || c == '/' || c == '\'' || c == '"') { u->bad = 1; return 0; }
+    *b = u->col;
+    while (u->col < u->len && !strchr(" \t,/", u->rec[u->col])) u->col++;
+    *e = u->col;
+    for (size_t i = *b; i < *e; i++) if (u->rec[i] == '*') { u->bad = 1; return 0; }
+    while (u->col < u->len && (u->rec[u->col] == ' ' || u->rec[u->col] == '\t')) u->col++;
+    if (u->col < u->len && u->rec[u->col] == ',') u->col++;
+    return 1;
+}
+
+static int rd_int(rd_unit *u)
+{
+    size_t b, e;
+    if (!rd_item(u, &b, &e)) return 0;
+    size_t k = b + ((u->rec[b] == '+' || u->rec[b] == '-') ? 1 : 0);
+    if (k == e || e - b > 11) { u->bad = 1; return 0; }
+    for (size_t i = k; i < e; i++) if (!isdigit((unsigned char)u->rec[i])) { u->bad = 1; return 0; }
+    char tmp[16];
+    memcpy(tmp, u->rec + b, e - b); tmp[e - b] = 0;
+    long long v = strtoll(tmp, NULL, 10);
+    if (v > 2147483647LL || v < -2147483647LL - 1) { u->bad = 1; return 0; }
+    return (int)v;
+}
+
+static double rd_real(rd_unit *u)
+{
+    size_t b, e;
+    char tmp[80];
+    if (!rd_item(u, &b, &e)) return 0.0;
+    if (e - b > 70) { u->bad = 1; return 0.0; }
+    size_t n = 0, mark = 0; int has_e = 0;
+    for (size_t i = b; i < e; i++) {
+        char c = u->rec[i];
+        if (c == 'd' || c == 'D' || c == 'E') c = 'e';
+        if (!(isdigit((unsigned char)c) || c == '+' || c == '-' || c == '.' || c == 'e')) { u->bad = 1; return 0.0; }
+        if (c == 'e') has_e = 1;
+        if ((c == '+' || c == '-') && n > 0) mark = n;
+        tmp[n++] = c;
+    }
+    tmp[n] = 0;
+    if (!has_e && mark > 0 && (tmp[mark - 1] == '.' || isdigit((unsigned char)tmp[mark - 1]))) {   /* 1.0-11 = 1.0e-11 */
+        memmove(tmp + mark + 1, tmp + mark, n - mark + 1);
+        tmp[mark] = 'e';
+    }
     char *end;
-    double v = strtod(tmp, &end);
-    if (*end) *ok = 0;
+    double v = strtod(tmp, &end);                /* correctly rounded, as libgfortran's conversion */
+    if (end == tmp || *end || !isfinite(v)) { u->bad = 1; return 0.0; }
     return v;
 }
 
+static void rd_word(rd_unit *u) { size_t b, e; (void)rd_item(u, &b, &e); }
+
+/* Limits of the reference binary (its STOP messages: "too many ..."; ref_lamda_corpus.json) */
+enum { RXO_MAXLEV = 2999, RXO_MAXLINE = 99999, RXO_MAXCOLL = 99999, RXO_MAXTEMP = 99 };
+
 rxo_mol *rxo_mol_load(const char *path, char *err, size_t errlen)
 {
-    FILE *f = fopen(path, "r");
+    FILE *f = fopen(path, "rb");
     if (!f) { set_err(err, errlen, "cannot open molecular data file"); return NULL; }
     rxo_mol *m = (rxo_mol *)calloc(1, sizeof *m);
-    enum { LB = 1 << 16 };
-    char *buf = (char *)malloc(LB);
-    char *p; int ok = 1;
-#define NEXT() do { if (!rd_line(f, buf, LB)) { ok = 0; goto fail; } p = buf; } while (0)
-    NEXT();            /* !MOLECULE */
-    NEXT();            /* name */
-    NEXT();            /* !MOLECULAR WEIGHT */
-    NEXT(); m->amass = rd_real(&p, &ok);
-    NEXT();            /* !NUMBER OF ENERGY LEVELS */
-    NEXT(); m->nlev = (int)rd_real(&p, &ok);
-    if (!ok || m->nlev < 2 || m->nlev > 2999) { ok = 0; goto fail; }
+    rd_unit U = {f, NULL, 0, 0, 0, 1, 0}, *u = &U;
+#define CHECK(cond) do { if (u->bad || !(cond)) goto fail; } while (0)
+    rd_skip(u);                                   /* !MOLECULE */
+    rd_skip(u);                                   /* the name, (a) */
+    rd_skip(u);                                   /* !MOLECULAR WEIGHT */
+    rd_begin(u); m->amass = rd_real(u); rd_end(u);
+    rd_skip(u);                                   /* !NUMBER OF ENERGY LEVELS */
+    rd_begin(u); m->nlev = rd_int(u); rd_end(u);
+    CHECK(m->nlev >= 2 && m->nlev <= RXO_MAXLEV);             /* "too few / too many energy levels defined" */
     m->eterm = (double *)calloc(m->nlev, sizeof(double));
     m->gstat = (double *)calloc(m->nlev, sizeof(double));
-    NEXT();            /* !LEVEL + ... */
-    for (int i = 0; i < m->nlev; i++) {
-        NEXT(); (void)rd_real(&p, &ok);
-        m->eterm[i] = rd_real(&p, &ok);
-        m->gstat[i] = rd_real(&p, &ok);
+    rd_skip(u);                                   /* !LEVEL + ENERGIES + WEIGHT + QN */
+    for (int i = 0; i < m->nlev; i++) {           /* stored by position; number, energy, weight and the quantum-number string are read */
+        rd_begin(u);
+        int no = rd_int(u);
+        m->eterm[i] = rd_real(u);
+        m->gstat[i] = rd_real(u);
+        rd_word(u);
+        rd_end(u);
+        CHECK(no >= 1 && no <= m->nlev);          /* "illegal level number" */
     }
-    NEXT();            /* !NUMBER OF RADIATIVE TRANSITIONS */
-    NEXT(); m->nline = (int)rd_real(&p, &ok);
-    if (!ok || m->nline < 1 || m->nline > 99999) { ok = 0; goto fail; }
+    rd_skip(u);                                   /* !NUMBER OF RADIATIVE TRANSITIONS */
+    rd_begin(u); m->nline = rd_int(u); rd_end(u);
+    CHECK(m->nline >= 1 && m->nline <= RXO_MAXLINE);
     m->iupp = (int *)calloc(m->nline, sizeof(int));
     m->ilow = (int *)calloc(m->nline, sizeof(int));
     m->aeinst = (double *)calloc(m->nline, sizeof(double));
     m->spfreq = (double *)calloc(m->nline, sizeof(double));
     m->eup = (double *)calloc(m->nline, sizeof(double));
     m->xnu = (double *)calloc(m->nline, sizeof(double));
-    NEXT();            /* !TRANS + ... */
+    rd_skip(u);                                   /* !TRANS + ... */
     for (int l = 0; l < m->nline; l++) {
-        NEXT(); (void)rd_real(&p, &ok);
-        m->iupp[l] = (int)rd_real(&p, &ok);
-        m->ilow[l] = (int)rd_real(&p, &ok);
-        m->aeinst[l] = rd_real(&p, &ok);
-        m->spfreq[l] = rd_real(&p, &ok);
-        m->eup[l] = rd_real(&p, &ok);
-        if (!ok || m->iupp[l] < 1 || m->iupp[l] > m->nlev ||
-            m->ilow[l] < 1 || m->ilow[l] > m->nlev) { ok = 0; goto fail; }
+        rd_begin(u);
+        int no = rd_int(u);
+        m->iupp[l] = rd_int(u);
+        m->ilow[l] = rd_int(u);
+        m->aeinst[l] = rd_real(u);
+        m->spfreq[l] = rd_real(u);
+        m->eup[l] = rd_real(u);
+        rd_end(u);
+        CHECK(no >= 1 && no <= m->nline);         /* "illegal line number" */
+        /* (for a level index outside 1..nlev the binary reads outside eterm -- eterm(0) is amass: not restated, an error) */
+        CHECK(m->iupp[l] >= 1 && m->iupp[l] <= m->nlev && m->ilow[l] >= 1 && m->ilow[l] <= m->nlev);
         /* xnu = energy difference, NOT the listed frequency [BIN 0x1d735-0x1d745] */
         m->xnu[l] = m->eterm[m->iupp[l] - 1] - m->eterm[m->ilow[l] - 1];
-        if (m->xnu[l] < 1e-30) { ok = 0; goto fail; } /* "illegal line frequency" */
+        CHECK(!(m->xnu[l] < 1e-30));              /* "illegal line frequency" */
     }
-    NEXT();            /* !NUMBER OF COLL PARTNERS */
-    NEXT(); m->npart = (int)rd_real(&p, &ok);
-    if (!ok || m->npart < 1 || m->npart > RXO_MAXPART) { ok = 0; goto fail; }
+    rd_skip(u);                                   /* !NUMBER OF COLL PARTNERS */
+    rd_begin(u); m->npart = rd_int(u); rd_end(u);
+    CHECK(m->npart >= 1 && m->npart <= RXO_MAXPART);
     for (int ip = 0; ip < m->npart; ip++) {
-        NEXT();        /* !COLLISIONS BETWEEN */
-        NEXT(); m->part_id[ip] = (int)rd_real(&p, &ok);   /* first integer on the line */
-        if (!ok || m->part_id[ip] < 1 || m->part_id[ip] > RXO_MAXPART) { ok = 0; goto fail; }
-        NEXT();        /* !NUMBER OF COLL TRANS */
-        NEXT(); m->ncoll[ip] = (int)rd_real(&p, &ok);
-        NEXT();        /* !NUMBER OF COLL TEMPS */
-        NEXT(); m->ntemp[ip] = (int)rd_real(&p, &ok);
-        if (!ok || m->ncoll[ip] < 1 || m->ntemp[ip] < 1) { ok = 0; goto fail; }
+        rd_skip(u);                               /* !COLLISIONS BETWEEN */
+        /* (i1,a): the FIRST CHARACTER of the record is the partner id (a blank reads as 0) */
+        CHECK(rd_record(u));
+        u->fresh = 1;
+        {
+            char c = u->len ? u->rec[0] : ' ';
+            CHECK(c == ' ' || isdigit((unsigned char)c));
+            m->part_id[ip] = c == ' ' ? 0 : c - '0';
+        }
+        CHECK(m->part_id[ip] >= 1 && m->part_id[ip] <= 7);    /* (0 reads density(0); 8, 9: never set by pyradex, core.py:476-482) */
+        rd_skip(u);                               /* !NUMBER OF COLL TRANS */
+        rd_begin(u); m->ncoll[ip] = rd_int(u); rd_end(u);
+        CHECK(m->ncoll[ip] >= 1 && m->ncoll[ip] <= RXO_MAXCOLL);
+        rd_skip(u);                               /* !NUMBER OF COLL TEMPS */
+        rd_begin(u); m->ntemp[ip] = rd_int(u); rd_end(u);
+        CHECK(m->ntemp[ip] >= 1 && m->ntemp[ip] <= RXO_MAXTEMP);   /* (0: the binary goes on with a column it never read) */
         m->temp[ip] = (double *)calloc(m->ntemp[ip], sizeof(double));
         m->lcu[ip] = (int *)calloc(m->ncoll[ip], sizeof(int));
         m->lcl[ip] = (int *)calloc(m->ncoll[ip], sizeof(int));
         m->coll[ip] = (double *)calloc((size_t)m->ncoll[ip] * m->ntemp[ip], sizeof(double));
-        NEXT();        /* !COLL TEMPS */
-        NEXT();
-        for (int t = 0; t < m->ntemp[ip]; t++) m->temp[ip][t] = rd_real(&p, &ok);
-        NEXT();        /* !TRANS + UP + LOW + COLLRATES */
-        for (int c = 0; c < m->ncoll[ip]; c++) {
-            NEXT(); (void)rd_real(&p, &ok);
-            m->lcu[ip][c] = (int)rd_real(&p, &ok);
-            m->lcl[ip][c] = (int)rd_real(&p, &ok);
-            for (int t = 0; t < m->ntemp[ip]; t++)
-                m->coll[ip][(size_t)c * m->ntemp[ip] + t] = rd_real(&p, &ok);
-            if (!ok || m->lcu[ip][c] < 1 || m->lcu[ip][c] > m->nlev ||
-                m->lcl[ip][c] < 1 || m->lcl[ip][c] > m->nlev) { ok = 0; goto fail; }
+        rd_skip(u);                               /* !COLL TEMPS */
+        rd_begin(u);
+        for (int t = 0; t < m->ntemp[ip]; t++) m->temp[ip][t] = rd_real(u);
+        rd_end(u);
+        CHECK(1);
+        rd_skip(u);                               /* !TRANS + UP + LOW + COLLRATES */
+        int kept = 0;
+        const int declared = m->ncoll[ip];
+        for (int c = 0; c < declared; c++) {
+            rd_begin(u);
+            int no = rd_int(u), up = rd_int(u), lo = rd_int(u);
+            double *K = m->coll[ip] + (size_t)kept * m->ntemp[ip];
+            for (int t = 0; t < m->ntemp[ip]; t++) K[t] = rd_real(u);
+            rd_end(u);
+            CHECK(no >= 1 && no <= declared);     /* "illegal collision number" */
+            CHECK(up >= 1 && lo >= 1 && up <= RXO_MAXLEV && lo <= RXO_MAXLEV);
+            if (up > m->nlev || lo > m->nlev) continue;        /* stored by the binary, never used: its loops run over 1..nlev */
+            m->lcu[ip][kept] = up; m->lcl[ip][kept] = lo;
+            kept++;
         }
+        m->ncoll[ip] = kept;
     }
-#undef NEXT
-    free(buf); fclose(f);
+#undef CHECK
+    free(U.rec); fclose(f);
     return m;
 fail:
-    free(buf); fclose(f);
+    free(U.rec); fclose(f);
     rxo_mol_free(m);
     set_err(err, errlen, "malformed LAMDA file");
     return NULL;
@@ -273,11 +361,13 @@ int rxo_rates(rxo_state *s)
     double tot = 0.0;
     for (int k = 0; k < RXO_MAXPART; k++) tot += s->density[k];
     s->totdens = tot;
-    for (int id = 1; id <= RXO_MAXPART; id++) {
-        double dens = s->density[id - 1];
-        int ip = -1;
-        for (int q = 0; q < m->npart; q++) if (m->part_id[q] == id) ip = q;
-        if (ip < 0 || !(dens > 0.0)) continue;
+    /* per partner, in file order: the interpolated rates go into a table colld(up,low) -- a pair listed twice keeps its LAST row --
+     * and crate += density(id) * colld; two partners with the same id both count (ref_lamda_corpus.json: ok_duplicate_rate_row,
+     * ok_duplicate_partner_id).  A negative rate is not an error in the binary (bad_negative_rate: crate < 0). */
+    double *tab = (double *)malloc(sizeof(double) * n * n);
+    for (int ip = 0; ip < m->npart; ip++) {
+        double dens = s->density[m->part_id[ip] - 1];
+        if (!(dens > 0.0)) continue;
         int nt = m->ntemp[ip];
         const double *T = m->temp[ip];
         int mode, it = 0; double t = 0.0;   /* mode 0: single column it; 1: lerp */
@@ -287,16 +377,19 @@ int rxo_rates(rxo_state *s)
         else {
             mode = 1;
             for (it = 0; it < nt - 1; it++) if (tk > T[it] && tk <= T[it + 1]) break;
-            t = (tk - T[it]) / (T[it + 1] - T[it]);
+            if (it >= nt - 1) { mode = 0; it = nt - 1; }       /* (temperatures out of order: no bracket found) */
+            else t = (tk - T[it]) / (T[it + 1] - T[it]);
         }
+        memset(tab, 0, sizeof(double) * n * n);
         for (int c = 0; c < m->ncoll[ip]; c++) {
             const double *K = m->coll[ip] + (size_t)c * nt;
             double colld = mode ? K[it] + t * (K[it + 1] - K[it]) : K[it];
-            if (colld < 0.0) return -1;
-            int iu = m->lcu[ip][c] - 1, il = m->lcl[ip][c] - 1;
-            s->crate[iu * n + il] += dens * colld;
+            if (colld < 0.0) colld = K[it];       /* a negative interpolate falls back to the lower grid column (no error): bad_negative_rate* */
+            tab[(m->lcu[ip][c] - 1) * n + (m->lcl[ip][c] - 1)] = colld;
         }
+        for (int k = 0; k < n * n; k++) s->crate[k] += dens * tab[k];
     }
+    free(tab);
     for (int iup = 0; iup < n; iup++)
         for (int ilo = 0; ilo < n; ilo++) {
             double ediff = m->eterm[iup] - m->eterm[ilo];

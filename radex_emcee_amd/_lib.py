@@ -43,7 +43,7 @@ class EngineLibraryMissing(ImportError):
 
 def build(fast: bool = False, force: bool = False) -> str:
     """Compile the HIP extension in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("rx_api.hip", "rx_kernel.hip.inc", "rx_refine.hip.inc", "rx_sampler.hip.inc", "rx_tables.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("rx_api.hip", "rx_kernel.hip.inc", "rx_refine.hip.inc", "rx_sampler.hip.inc", "rx_tables.h", "rx_lamda.h")]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "radex_emcee_amd.h"))
     stale = (not os.path.exists(LIB_PATH)
              or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs))

@@ -16,6 +16,7 @@
 #include "rx_kernel.hip.inc"
 #include "rx_sampler.hip.inc"
 #include "rx_tables.h"
+#include "rx_lamda.h"
 
 // Padded level counts the solve kernel is instantiated for (one fully unrolled
 // kernel each); rx_create picks the smallest one >= nlev.  41 = CO.
@@ -35,121 +36,13 @@ constexpr double H_FGAUS = 26.753802360251857;
 constexpr double H_THC_PY = 3.9728917142978573e-16;
 constexpr double H_FK_PY = 1.4387768775039338;
 
-struct Partner {
-    int id = 0, ncoll = 0, ntemp = 0;
-    std::vector<double> temps;
-    std::vector<int> lcu, lcl;
-    std::vector<double> coll;   // [ncoll][ntemp]
-};
+// The LAMDA reader is host-only code of its own (rx_lamda.h: also built by g++ with sanitizers for the corpus test)
+using rxl::Partner;
+using rxl::Molecule;
 
-struct Molecule {
-    int nlev = 0, nline = 0;
-    double amass = 0;
-    std::vector<double> eterm, gstat;
-    std::vector<int> iupp, ilow;
-    std::vector<double> aeinst, spfreq, eup, xnu;
-    std::vector<Partner> parts;
-};
-
-// --- LAMDA reader: positional, as readdata_ [BIN 0x1cf90-0x1e338] ------------
-struct LineReader {
-    FILE *f;
-    std::vector<char> buf;
-    char *p = nullptr;
-    bool ok = true;
-    explicit LineReader(FILE *ff) : f(ff), buf(1 << 16) {}
-    bool next() {
-        if (!fgets(buf.data(), (int)buf.size(), f)) { ok = false; return false; }
-        p = buf.data();
-        return true;
-    }
-    double real() {   // Fortran list-directed: blanks/commas separate, D exponents allowed
-        while (*p && (isspace((unsigned char)*p) || *p == ',')) ++p;
-        char tmp[64];
-        int k = 0;
-        while (*p && !isspace((unsigned char)*p) && *p != ',' && k < 63) {
-            char ch = *p++;
-            tmp[k++] = (ch == 'd' || ch == 'D') ? 'e' : ch;
-        }
-        tmp[k] = 0;
-        if (!k) { ok = false; return 0.0; }
-        char *end;
-        double v = strtod(tmp, &end);
-        if (*end) ok = false;
-        return v;
-    }
-    int integer() { return (int)real(); }
-};
-
-int load_lamda(const char *path, Molecule &m, std::string &err)
+int read_molecule(const char *path, Molecule &m, std::string &err)
 {
-    FILE *f = fopen(path, "r");
-    if (!f) { err = std::string("cannot open molecular data file: ") + path; return RX_E_IO; }
-    LineReader r(f);
-    auto fail = [&](const char *what) { fclose(f); err = std::string("malformed LAMDA file (") + what + "): " + path; return RX_E_IO; };
-    r.next(); r.next(); r.next();
-    if (!r.next()) return fail("weight");
-    m.amass = r.real();
-    r.next();
-    if (!r.next()) return fail("nlev");
-    m.nlev = r.integer();
-    if (!r.ok || m.nlev < 2 || m.nlev > 2999) return fail("nlev");
-    m.eterm.resize(m.nlev); m.gstat.resize(m.nlev);
-    r.next();
-    for (int i = 0; i < m.nlev; ++i) {
-        if (!r.next()) return fail("levels");
-        (void)r.real(); m.eterm[i] = r.real(); m.gstat[i] = r.real();
-    }
-    r.next();
-    if (!r.next()) return fail("nline");
-    m.nline = r.integer();
-    if (!r.ok || m.nline < 1 || m.nline > 99999) return fail("nline");
-    m.iupp.resize(m.nline); m.ilow.resize(m.nline); m.aeinst.resize(m.nline);
-    m.spfreq.resize(m.nline); m.eup.resize(m.nline); m.xnu.resize(m.nline);
-    r.next();
-    for (int l = 0; l < m.nline; ++l) {
-        if (!r.next()) return fail("lines");
-        (void)r.real();
-        m.iupp[l] = r.integer(); m.ilow[l] = r.integer();
-        m.aeinst[l] = r.real(); m.spfreq[l] = r.real(); m.eup[l] = r.real();
-        if (!r.ok || m.iupp[l] < 1 || m.iupp[l] > m.nlev || m.ilow[l] < 1 || m.ilow[l] > m.nlev)
-            return fail("line indices");
-        // xnu = eterm(iupp) - eterm(ilow), not the listed frequency [BIN 0x1d735-0x1d745]
-        m.xnu[l] = m.eterm[m.iupp[l] - 1] - m.eterm[m.ilow[l] - 1];
-        if (m.xnu[l] < 1e-30) return fail("illegal line frequency");
-    }
-    r.next();
-    if (!r.next()) return fail("npart");
-    int npart = r.integer();
-    if (!r.ok || npart < 1 || npart > RXK_MAXPART) return fail("npart");
-    m.parts.resize(npart);
-    for (int ip = 0; ip < npart; ++ip) {
-        Partner &P = m.parts[ip];
-        r.next();
-        if (!r.next()) return fail("partner id");
-        P.id = r.integer();
-        if (!r.ok || P.id < 1 || P.id > RXK_MAXPART) return fail("partner id");
-        r.next(); if (!r.next()) return fail("ncoll");
-        P.ncoll = r.integer();
-        r.next(); if (!r.next()) return fail("ntemp");
-        P.ntemp = r.integer();
-        if (!r.ok || P.ncoll < 1 || P.ntemp < 1) return fail("ncoll/ntemp");
-        P.temps.resize(P.ntemp); P.lcu.resize(P.ncoll); P.lcl.resize(P.ncoll);
-        P.coll.resize((size_t)P.ncoll * P.ntemp);
-        r.next(); if (!r.next()) return fail("temps");
-        for (int t = 0; t < P.ntemp; ++t) P.temps[t] = r.real();
-        r.next();
-        for (int c = 0; c < P.ncoll; ++c) {
-            if (!r.next()) return fail("rates");
-            (void)r.real();
-            P.lcu[c] = r.integer(); P.lcl[c] = r.integer();
-            for (int t = 0; t < P.ntemp; ++t) P.coll[(size_t)c * P.ntemp + t] = r.real();
-            if (!r.ok || P.lcu[c] < 1 || P.lcu[c] > m.nlev || P.lcl[c] < 1 || P.lcl[c] > m.nlev)
-                return fail("rate indices");
-        }
-    }
-    fclose(f);
-    return 0;
+    return rxl::load_lamda(path, m, err) == rxl::LAMDA_OK ? 0 : RX_E_IO;
 }
 
 int pick_nl(int nlev)
@@ -403,8 +296,10 @@ int build_tables(rx_handle *h)
             const int u = P.lcu[c] - 1, l = P.lcl[c] - 1;
             for (int t = 0; t < P.ntemp; ++t) {
                 const double v = P.coll[(size_t)c * P.ntemp + t];
-                K[((size_t)t * NL + u) * NL + l] += v;      // duplicates accumulate like crate(up,low) +=
-                K[((size_t)t * NL + l) * NL + u] = K[((size_t)t * NL + u) * NL + l];
+                // (a pair listed twice: the LAST row stands -- the reference writes its table colld(up,low), it does not add;
+                // tests/golden/ref_lamda_corpus.json: ok_duplicate_rate_row)
+                K[((size_t)t * NL + u) * NL + l] = v;
+                K[((size_t)t * NL + l) * NL + u] = v;
             }
         }
         double *dK = nullptr;
@@ -580,7 +475,7 @@ rx_handle *rx_create(const char *lamda_path, int method, double deltav_kms, int 
     if (!lamda_path || method < 1 || method > 3 || !(deltav_kms > 0) || device < 0) { seterr("bad argument"); return nullptr; }
     rx_handle *h = new rx_handle;
     h->device = device; h->method = method; h->deltav_kms = deltav_kms;
-    int rc = load_lamda(lamda_path, h->mol, h->err);
+    int rc = read_molecule(lamda_path, h->mol, h->err);
     if (!rc) rc = validate_molecule(h);
     if (!rc) { h->NL = pick_nl(h->mol.nlev); if (h->NL < 0) { h->err = "no kernel instantiation for this nlev"; rc = RX_E_UNSUPP; } }
     if (rc) { seterr(h->err); delete h; return nullptr; }

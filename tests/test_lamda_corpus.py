@@ -1,0 +1,183 @@
+"""Row a6 on ill-formed input: the LAMDA reader against what the REFERENCE BINARY's readdata_ does with the same files.
+
+tests/golden/lamda_corpus/ holds ~100 small files (mutations of toy6.dat, a 41- and a 70-level ladder) and
+tests/golden/ref_lamda_corpus.json what radex.so's own machine code made of each of them (make_ref_lamda_corpus.py: accepted ->
+the parsed tables and crate / ctot at two temperatures; STOP; an I/O condition libgfortran ends the run on; an input form the
+loader's shim does not implement) [/root/reference/emcee/pyradex/core.py:293-298, 570, 738-744: a bad file is an exception
+at construction].  Held to that list, on the CPU:
+
+  * the product's reader (radex_emcee_amd/csrc/rx_lamda.h, the code rx_create runs) built on its own by g++ with
+    AddressSanitizer + UBSan (`make -C radex_emcee_amd/csrc lamda-check`): every file accepted or rejected as the binary does,
+    no sanitizer report, the tables of accepted files equal to the binary's bit for bit;
+  * rx_create itself through the C ABI: a rejected file fails with RX_E_IO's message before any device is touched;
+  * the checker (oracle/radex_oracle.c): the same acceptance, tables AND crate / ctot equal to the binary's bit for bit.
+
+Where the readers are STRICTER than the binary -- it reads outside its arrays there, or goes on with a column it never read --
+the file and the reason are listed in STRICTER; everything else must agree."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CORPUS = os.path.join(ROOT, "tests", "golden", "lamda_corpus")
+
+from oracle import oracle as O                      # noqa: E402  (checker only)
+
+# accepted by the binary, rejected here on purpose
+STRICTER = {
+    "bad_line_upper_zero": "the binary reads eterm(0) for it -- that is amass, the word in front of the array",
+    "bad_line_lower_negative": "eterm(-2): outside the array",
+    "bad_rate_upper_zero": "colld(0, low): outside the table",
+    "bad_ntemp_zero": "no rate column exists; the binary goes on with a table it never wrote",
+}
+# accepted by the reader, but outside what the kernels' dense symmetric rate table represents: rx_create says RX_E_UNSUPP / RX_E_IO
+UNSUPPORTED_BY_KERNELS = {
+    "ok_ladder70": "molecule exceeds kernel limits",
+    "ok_upward_rate_listed": "E_up <= E_low",
+    "ok_level_rows_permuted": "E_up <= E_low",        # (levels are stored by position: 2 and 3 trade energies)
+    "ok_lower_energy_upper_level_collision": "E_up <= E_low",
+    "bad_rate_same_level": "E_up <= E_low",
+    "ok_duplicate_partner_id": "duplicate collision partner id",
+    "bad_negative_rate": "negative collision rate",
+    "bad_negative_rate_one_column": "negative collision rate",
+}
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "ref_lamda_corpus.json")))["files"]
+
+
+@pytest.fixture(scope="module")
+def checker():
+    d = os.path.join(ROOT, "radex_emcee_amd", "csrc")
+    subprocess.run(["make", "-C", d, "lamda-check"], check=True, capture_output=True, timeout=300)
+    return os.path.join(d, "rx_lamda_check")
+
+
+def _expect_accept(name, rec):
+    return rec["outcome"] == "ok" and name not in STRICTER
+
+
+def test_corpus_is_what_the_fixture_describes(ref):
+    files = sorted(f[:-4] for f in os.listdir(CORPUS) if f.endswith(".dat"))
+    assert files == sorted(ref) and len(files) >= 90
+    kinds = {}
+    for r in ref.values():
+        kinds[r["outcome"].split(":")[0]] = kinds.get(r["outcome"].split(":")[0], 0) + 1
+    assert kinds["ok"] >= 35 and kinds["stop"] >= 15 and kinds["io"] >= 15 and kinds["unsupported"] >= 2, kinds
+    assert all(n in ref and ref[n]["outcome"] == "ok" for n in list(STRICTER) + list(UNSUPPORTED_BY_KERNELS))
+
+
+def test_product_reader_under_sanitizers_against_the_binary(ref, checker):
+    for name, rec in sorted(ref.items()):
+        r = subprocess.run([checker, os.path.join(CORPUS, name + ".dat")], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+        assert r.returncode in (0, 3), (name, r.returncode, r.stderr[-2000:])          # anything else: a sanitizer report or a crash
+        assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (name, r.stderr[-2000:])
+        got = json.loads(r.stdout)
+        if not _expect_accept(name, rec):
+            assert r.returncode == 3 and got["rc"] == 2 and "malformed LAMDA file" in got["error"], (name, rec["outcome"], got)
+            continue
+        assert r.returncode == 0, (name, rec["outcome"], got.get("error"))
+        assert (got["nlev"], got["nline"], got["npart"]) == (rec["nlev"], rec["nline"], rec["npart"]), name
+        for k in ("eterm", "gstat", "aeinst", "spfreq", "xnu"):
+            assert np.array_equal(np.array(got[k]), np.array(rec[k])), (name, k)
+        for k in ("iupp", "ilow"):
+            assert got[k] == rec[k], (name, k)
+        # the collisional half is pinned through the checker below: the product's raw partner tables must be the checker's
+        m = O.Molecule(os.path.join(CORPUS, name + ".dat"))
+        pt = m.partner_tables()
+        assert len(pt) == len(got["partners"])
+        for (pid, temps, lcu, lcl, coll), g in zip(pt, got["partners"]):
+            assert pid == g["id"] and g["ntemp"] == len(temps) and g["ncoll"] == len(lcu), name
+            assert np.array_equal(temps, np.array(g["temps"])) and list(lcu) == g["lcu"] and list(lcl) == g["lcl"], name
+            assert np.array_equal(coll.ravel(), np.array(g["coll"], dtype=np.float64)), name
+
+
+def test_checker_reader_and_rates_against_the_binary(ref):
+    n_ok = 0
+    for name, rec in sorted(ref.items()):
+        path = os.path.join(CORPUS, name + ".dat")
+        if not _expect_accept(name, rec):
+            with pytest.raises(ValueError):
+                O.Molecule(path)
+            continue
+        m = O.Molecule(path)
+        assert (m.nlev, m.nline, m.npart) == (rec["nlev"], rec["nline"], rec["npart"]), name
+        for k in ("eterm", "gstat", "aeinst", "spfreq", "xnu"):
+            assert np.array_equal(getattr(m, k), np.array(rec[k])), (name, k)
+        assert list(m.iupp) == rec["iupp"] and list(m.ilow) == rec["ilow"], name
+        for pt in rec["points"]:                                       # readdata_'s rate half on the same file: crate, ctot
+            st = O.State(m)
+            st.set_density({int(k): v for k, v in pt["density"].items()})
+            st.s.tkin = pt["tkin"]
+            assert st.rates() == 0, name
+            assert np.array_equal(st.arr("crate"), np.array(pt["crate"])), (name, pt["tkin"])
+            assert np.array_equal(st.arr("ctot"), np.array(pt["ctot"])), (name, pt["tkin"])
+        n_ok += 1
+    assert n_ok >= 30
+
+
+def test_rx_create_rejects_what_the_binary_rejects(ref):
+    """Through the C ABI: the parse (and the kernels' own limits) come before the device is looked for, so this runs without a GPU --
+    an accepted file ends in "no usable HIP device" here, in a handle on the GPU box."""
+    from radex_emcee_amd import _lib
+    L = _lib.load()
+    for name, rec in sorted(ref.items()):
+        err = C.create_string_buffer(512)
+        h = L.rx_create(os.path.join(CORPUS, name + ".dat").encode(), 2, 1.0, 0, err, 512)
+        msg = err.value.decode("latin-1")
+        if h:
+            L.rx_destroy(h)
+        if not _expect_accept(name, rec):
+            assert not h and "malformed LAMDA file" in msg, (name, rec["outcome"], msg)
+        elif name in UNSUPPORTED_BY_KERNELS:
+            assert not h and UNSUPPORTED_BY_KERNELS[name] in msg, (name, msg)
+        else:
+            assert h or "no usable HIP device" in msg, (name, msg)
+
+
+@pytest.mark.gpu
+def test_gpu_solves_on_every_accepted_corpus_file(ref):
+    """Every corpus file the binary accepts and the kernels support, solved on the GPU (rx_create -> rx_solve_batch) against the
+    checker on the same file -- whose crate / ctot for it are the binary's bit for bit (above): duplicate rate rows (the last one
+    stands), rows naming levels above nlev (ignored), temperatures out of order, a single temperature column, values continued
+    on the next record, two partners one of which has no density, the 41-level ladder."""
+    from radex_emcee_amd.engine import Engine
+    from radex_emcee_amd._lib import RX_OK
+    rng = np.random.default_rng(11)
+    done = []
+    for name, rec in sorted(ref.items()):
+        if not _expect_accept(name, rec) or name in UNSUPPORTED_BY_KERNELS:
+            continue
+        path = os.path.join(CORPUS, name + ".dat")
+        e = Engine(path)
+        m = O.Molecule(path)
+        assert e.nlev == rec["nlev"] and e.nline == rec["nline"] and np.array_equal(e.xnu, np.array(rec["xnu"])), name
+        e.set_source(2.73)
+        N = 24
+        tkin = 10.0 ** rng.uniform(0.8, 2.6, N)
+        cd = 10.0 ** rng.uniform(12.5, 16.5, N)
+        dens = 10.0 ** rng.uniform(2.0, 6.0, (N, e.npart))
+        if name == "ok_partner_without_density":
+            dens[:, 1] = 0.0
+        got = e.solve_batch(tkin, cd, dens)
+        ncmp = 0
+        for w in range(N):
+            # (two partners with one id cannot reach here: UNSUPPORTED_BY_KERNELS)
+            r = O.solve_state(m, 2.73, {pid: dens[w, k] for k, pid in enumerate(e.partner_ids)}, tkin[w], cd[w])
+            if not np.all(np.isfinite(r["xpop"])) or r["niter"] >= 200:
+                continue
+            assert got["status"][w] == RX_OK and got["niter"][w] == r["niter"], (name, w, got["niter"][w], r["niter"])
+            tol = 1e-6 * np.abs(r["xpop"]) + 1e-14
+            assert np.all(np.abs(got["xpop"][w] - r["xpop"]) <= tol), (name, w)
+            ncmp += 1
+        assert ncmp >= N // 2 or name == "bad_negative_einstein_a", (name, ncmp)
+        done.append(name)
+        e.close()
+    assert len(done) >= 25, done
