@@ -261,6 +261,15 @@ int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwal
                           void *ipc_handle_out);
 void *rx_sampler_peer_base(rx_handle *h);
 int rx_sampler_peer_connect(rx_handle *h, const void *ipc_handles, void *const *bases);
+/* The identity of the handle's GPU that means the same thing in every process of the node whatever *_VISIBLE_DEVICES says: its
+ * PCI bus id ("0000:c1:00.0", NUL-terminated, RX_BUS_ID_BYTES).  rx_sampler_peer_set_bus_ids: every rank's id in rank order
+ * ([nranks][RX_BUS_ID_BYTES]), given BEFORE rx_sampler_peer_connect: which replicas share this GPU (-> its compute units are
+ * split) and which GPU a remote replica lives on (-> hipDeviceCanAccessPeer, where that GPU is visible to this process) are
+ * then decided from the ids, not from what hipPointerGetAttributes says about an IPC mapping (which may name the OPENING device
+ * where the owner is not visible).  Without ids the pointer attributes are used, as before.  NULL forgets them.              */
+#define RX_BUS_ID_BYTES 32
+int rx_device_bus_id(rx_handle *h, char *out);
+int rx_sampler_peer_set_bus_ids(rx_handle *h, const char *bus_ids);
 int rx_sampler_peer_begin(rx_handle *h, const double *d_coords, const double *d_lnp,
                           const int32_t *d_naccept, void *stream);
 int rx_sampler_peer_run(rx_handle *h, double a, uint64_t seed, int64_t step0, int nsteps,

@@ -31,10 +31,12 @@ EXPORTS = [
     "rx_sampler_stats", "rx_lnprior_batch", "rx_set_sampler_speculation", "rx_sampler_spec_stats",
     "rx_sampler_peer_same_device", "rx_set_sampler_stall_ms", "rx_sampler_peer_abort", "rx_peer_topology",
     "rx_sampler_peer_disconnect", "rx_set_refinement", "rx_set_refinement_counting", "rx_refinement_counters", "rx_background",
+    "rx_device_bus_id", "rx_sampler_peer_set_bus_ids",
 ]
 ABI_VERSION = 7
 RX_MAX_RANKS = 8
 RX_IPC_HANDLE_BYTES = 64
+RX_BUS_ID_BYTES = 32
 
 
 class EngineLibraryMissing(ImportError):
@@ -134,6 +136,8 @@ def load():
     L.rx_sampler_peer_base.argtypes = [vp]
     L.rx_sampler_peer_base.restype = vp
     L.rx_sampler_peer_connect.argtypes = [vp, vp, vp]
+    L.rx_device_bus_id.argtypes = [vp, C.c_char_p]
+    L.rx_sampler_peer_set_bus_ids.argtypes = [vp, C.c_char_p]
     L.rx_sampler_peer_begin.argtypes = [vp, vp, vp, vp, vp]
     L.rx_sampler_peer_run.argtypes = [vp, C.c_double, u64, i64, C.c_int, vp, vp, vp, vp]
     L.rx_sampler_peer_finish.argtypes = [vp, vp, vp, vp, vp]

@@ -124,6 +124,7 @@ struct rx_handle {
         bool connected = false, begun = false;
         int same_device = 1;                     // ranks whose replica lives on THIS device (own included): they share its CUs
         int memkind = 0;                         // 1 fine-grained, 2 uncached, 3 plain hipMalloc
+        std::vector<std::string> bus_ids;        // PCI bus id of every rank's GPU (rx_sampler_peer_set_bus_ids), or empty
     } peer;
     unsigned int *d_order_cnt = nullptr;
     int force_occ = 0;               // 0: choose by batch size; 1 / 2: wavefronts per SIMD (rx_set_waves_per_simd)
@@ -1193,6 +1194,29 @@ int rx_sampler_peer_setup(rx_handle *h, int nranks, int rank, int nens, int nwal
 
 void *rx_sampler_peer_base(rx_handle *h) { return h ? (void *)h->peer.own : nullptr; }
 
+int rx_device_bus_id(rx_handle *h, char *out)
+{
+    if (!h || !out) return RX_E_ARG;
+    memset(out, 0, RX_BUS_ID_BYTES);
+    HIPCHK(h, hipDeviceGetPCIBusId(out, RX_BUS_ID_BYTES - 1, h->device));
+    return 0;
+}
+
+int rx_sampler_peer_set_bus_ids(rx_handle *h, const char *bus_ids)
+{
+    if (!h) return RX_E_ARG;
+    rx_handle::Peer &P = h->peer;
+    P.bus_ids.clear();
+    if (!bus_ids) return 0;
+    if (!P.own) { h->err = "rx_sampler_peer_set_bus_ids: call rx_sampler_peer_setup first"; return RX_E_STATE; }
+    for (int r = 0; r < P.nranks; ++r) {
+        const char *b = bus_ids + (size_t)r * RX_BUS_ID_BYTES;
+        P.bus_ids.emplace_back(b, strnlen(b, RX_BUS_ID_BYTES));
+        if (P.bus_ids.back().empty()) { P.bus_ids.clear(); h->err = "rx_sampler_peer_set_bus_ids: empty id"; return RX_E_ARG; }
+    }
+    return 0;
+}
+
 int rx_sampler_peer_connect(rx_handle *h, const void *ipc_handles, void *const *bases)
 {
     if (!h || (!ipc_handles && !bases)) return RX_E_ARG;
@@ -1219,9 +1243,27 @@ int rx_sampler_peer_connect(rx_handle *h, const void *ipc_handles, void *const *
     // hipDeviceCanAccessPeer.  A mapping whose device cannot be told is treated as unreachable -> RX_E_UNSUPP, and the
     // caller falls back to half-steps + all-gather on all ranks.
     P.same_device = 0;
+    const bool by_id = (int)P.bus_ids.size() == P.nranks;
     for (int r = 0; r < P.nranks; ++r) {
         hipPointerAttribute_t at;
         if (r == P.rank) { ++P.same_device; continue; }
+        if (by_id) {
+            // the ranks' own word for their GPUs (PCI bus ids): what an IPC mapping's pointer attributes say is not relied on
+            if (P.bus_ids[r] == P.bus_ids[P.rank]) { ++P.same_device; continue; }
+            int dev = -1, can = 0;
+            if (hipDeviceGetByPCIBusId(&dev, P.bus_ids[r].c_str()) != hipSuccess) {
+                // the peer's GPU is not visible to this process (one GPU per process): nothing to ask hipDeviceCanAccessPeer about;
+                // the mapping was opened with lazy peer access and is READ below -- an unreachable block fails there, in an API call
+                (void)hipGetLastError();
+                continue;
+            }
+            if (hipDeviceCanAccessPeer(&can, h->device, dev) != hipSuccess || !can) {
+                (void)hipGetLastError();
+                h->err = "rx_sampler_peer_connect: this device has no peer access to the device of rank " + std::to_string(r) + " (" + P.bus_ids[r] + ")";
+                return RX_E_UNSUPP;
+            }
+            continue;
+        }
         if (hipPointerGetAttributes(&at, P.base[r]) != hipSuccess) {
             (void)hipGetLastError();
             h->err = "rx_sampler_peer_connect: cannot tell which device a peer's replica lives on";

@@ -323,8 +323,20 @@ class Engine:
     def sampler_peer_base(self):
         return self._L.rx_sampler_peer_base(self._h)
 
-    def sampler_peer_connect(self, ipc_handles=None, bases=None):
-        """ipc_handles: one 64-byte handle per rank, in rank order -- or bases: device pointers (same process)."""
+    def bus_id(self):
+        """PCI bus id of the handle's GPU: the same string in every process of the node (rx_device_bus_id)."""
+        buf = C.create_string_buffer(_lib.RX_BUS_ID_BYTES)
+        self._chk(self._L.rx_device_bus_id(self._h, buf), "rx_device_bus_id")
+        return buf.value.decode()
+
+    def sampler_peer_connect(self, ipc_handles=None, bases=None, bus_ids=None):
+        """ipc_handles: one 64-byte handle per rank, in rank order -- or bases: device pointers (same process).
+        bus_ids: every rank's Engine.bus_id() in rank order: same-GPU / peer-access decisions are taken from them."""
+        if bus_ids is not None:
+            blob = b"".join(b.encode().ljust(_lib.RX_BUS_ID_BYTES, b"\0")[:_lib.RX_BUS_ID_BYTES] for b in bus_ids)
+            self._chk(self._L.rx_sampler_peer_set_bus_ids(self._h, blob), "rx_sampler_peer_set_bus_ids")
+        else:
+            self._chk(self._L.rx_sampler_peer_set_bus_ids(self._h, None), "rx_sampler_peer_set_bus_ids")
         if ipc_handles is not None:
             blob = b"".join(bytes(x) for x in ipc_handles)
             buf = C.create_string_buffer(blob, len(blob))

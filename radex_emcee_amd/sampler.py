@@ -617,8 +617,12 @@ class DeviceEnsembleSampler:
             handle = eng.sampler_peer_setup(self.world, self.rank, self.nens, self.nwalkers, self.ndim // 4)
         except EngineError as exc:
             err = str(exc)
+        try:
+            bus = eng.bus_id()                         # the GPU's name that means the same in every process of the node
+        except EngineError:
+            bus = None
         me = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
-              os.environ.get("CUDA_VISIBLE_DEVICES"), eng.device)
+              os.environ.get("CUDA_VISIBLE_DEVICES"), eng.device, bus)
         infos = self._gather_objects((handle, err, me))
         bad = [i for i, (_, e, _) in enumerate(infos) if e]
         if not bad and err is None:
@@ -642,7 +646,8 @@ class DeviceEnsembleSampler:
             # splits the compute units; an explicit limit of an earlier set-up must not outlive it)
             eng.set_sampler_grid_limit(0)
             try:
-                eng.sampler_peer_connect(ipc_handles=[h for (h, _, _) in infos])
+                ids = [m[5] for (_, _, m) in infos]
+                eng.sampler_peer_connect(ipc_handles=[h for (h, _, _) in infos], bus_ids=ids if all(ids) else None)
             except EngineError as exc:
                 err = str(exc)
             errs = self._gather_objects(err)

@@ -82,8 +82,13 @@ for shape, nw, nsteps in (("config2", 1024, 14), ("config4", 256, 5)):
     bases = [e.sampler_peer_base() for e in engs]
     assert all(bases)
     state = []
+    import re
+    ids = [e.bus_id() for e in engs]                      # (PCI bus id: the GPU's name in every process of the node)
+    assert ids[0] == ids[1] and re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", ids[0]), ids
     for r, e in enumerate(engs):
-        e.sampler_peer_connect(bases=bases)
+        # the first shape by bus ids (both replicas on this GPU), the second by what the pointer attributes say
+        e.sampler_peer_connect(bases=bases, bus_ids=ids if shape == "config2" else None)
+        assert e.sampler_peer_same_device() == 2
         state.append((torch.from_numpy(np.ascontiguousarray(p0)).to(dev), lnp0.clone(), torch.zeros(nw, dtype=torch.int32, device=dev),
                       torch.zeros(nsteps, nw, ndim, dtype=torch.float64, device=dev),
                       torch.zeros(nsteps, nw, dtype=torch.float64, device=dev)))

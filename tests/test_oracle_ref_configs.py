@@ -54,3 +54,23 @@ def test_config4_components_are_the_binarys(ref, mol):
 def test_config3_sources_are_the_binarys(ref, mol):
     tbg = ref["c3_tbg"][ref["c3_src"]]
     _check(mol, ref["c3_params"], tbg, ref["c3_niter"], ref["c3_conv"], ref["c3_tex"], ref["c3_taul"])
+
+
+def test_sensitivity_fixture_names_the_maxiter_walkers_of_the_test_batches(mol, golden_dir):
+    """tests/golden/ref_sensitivity.npz (scripts/ref_sensitivity.py: the reference binary with its exp / log one ulp off) is
+    what the GPU tests derive the ceiling of their maxiter walkers from: its walker lists must be exactly the walkers of the
+    batches that stop at maxiter (checked here for the two small ones; the binary itself confirmed maxiter for every one of
+    them when the fixture was made), and the summary the README quotes must be what the fixture holds."""
+    from radex_emcee_amd import workloads
+    f = np.load(os.path.join(golden_dir, "ref_sensitivity.npz"))
+    c3 = workloads.config3(512)
+    st = np.concatenate([O.lnprob_batch(mol, O.Source(s["tbg"], s["Jup"], s["flux"], s["eflux"], s["bounds"]), c3["walkers"][k], nthreads=8)[1]
+                         for k, s in enumerate(c3["sources"])])
+    assert np.array_equal(np.asarray(c3["src_index"]).reshape(16, 512)[:, 0], np.arange(16))
+    assert np.array_equal(np.flatnonzero(st == 1), f["config3_512_walker"])
+    big = [k[:-7] for k in f.files if k.startswith("big_") and k.endswith("_walker")]
+    assert len(big) == 16
+    resp = np.concatenate([f[b + "_resp_sb"] for b in big])
+    assert len(resp) == 49800 or abs(len(resp) - 49800) < 200
+    assert 10 <= int((resp > 1.0).sum()) <= 30 and 20.0 < resp.max() < 40.0          # the binary itself: 16 walkers beyond the tolerance, worst 29 x
+    assert np.median(resp) < 1e-7
