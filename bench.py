@@ -468,7 +468,10 @@ def main():
             barrier()
             return time.perf_counter() - ts, state_sha1(fin)
 
-        for name, ndim, nwk, nst in (("config2", 4, 1024, 60), ("config4", 8, 2048, 12), ("config5", 4, 65536, 6)):
+        # (steps per timed call: a call carries a fixed cost that is not the schedule's -- two host barriers of the process group around
+        # the timed region, state to and from the host; at 12 steps of 0.8 ms that was 15 % of config 4's figure in the shared-GPU
+        # rehearsals; the reference's calls are hundreds to thousands of steps, emcee_radex.py:496-499)
+        for name, ndim, nwk, nst in (("config2", 4, 1024, 120), ("config4", 8, 2048, 48), ("config5", 4, 65536, 12)):
             if name == "config2" and world == 1:
                 continue                                 # (N = 1: this shape is `sampler_config2_prior_box` below, with the kernel's counters)
             try:

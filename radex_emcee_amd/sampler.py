@@ -784,7 +784,8 @@ class DeviceEnsembleSampler:
         if t.is_cuda and self._dist.get_backend(self.group) == "gloo":     # (rehearsals: ranks that share one GPU)
             h = t.cpu()
             self._dist.broadcast(h, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-            t.copy_(h)
+            if self.rank != 0:
+                t.copy_(h)
         else:
             self._dist.broadcast(t, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
 
@@ -807,20 +808,40 @@ class DeviceEnsembleSampler:
                 self._sharded = sharded
 
     def _run_rank0(self, nsteps, chain, chain_lnp, broadcast=True):
-        """One run_mcmc call under "rank0".  An error on rank 0 is raised on EVERY rank."""
+        """One run_mcmc call under "rank0": rank 0 advances the ensemble, then ONE broadcast hands the state to the others --
+        a status word, positions, log-probabilities and acceptance counts packed into one buffer (a collective per tensor, or an
+        object gather for the status, costs more than the 40 KB they move); the stored chain follows in a second one.  An error on
+        rank 0 travels in the status word and is raised on EVERY rank."""
+        import torch
         from .engine import EngineError
+        N, nd = self.N, self.ndim
+        pack = getattr(self, "_pack", None)
+        if pack is None or pack.numel() != 1 + N * nd + 2 * N:
+            pack = self._pack = torch.zeros(1 + N * nd + 2 * N, dtype=torch.float64, device=self.coords.device)
         err = None
         if self.rank == 0:
             try:
                 self._unsharded(nsteps, chain, chain_lnp)
             except EngineError as exc:
-                err = "rank-0 run: %s" % exc
-        bad = self._agree(err)
-        if bad:
-            raise EngineError("sampler (schedule rank0), rank %d: %s" % bad[0])
+                err = exc
+            pack[0] = 0.0 if err is None else 1.0
+            pack[1:1 + N * nd].copy_(self.coords.reshape(-1))
+            pack[1 + N * nd:1 + N * nd + N].copy_(self.lnp)
+            pack[1 + N * nd + N:].copy_(self.naccept)           # (int32 counts are exact in a double)
+        if broadcast or err is not None:
+            self._bcast(pack)
+        if self.rank == 0 and err is not None:
+            raise err
         if broadcast:
-            for t in (self.coords, self.lnp, self.naccept) + ((chain, chain_lnp) if self.broadcast_chain else ()):
-                self._bcast(t)
+            if float(pack[0]) != 0.0:
+                raise EngineError("sampler (schedule rank0): the run failed on rank 0 (its message is on rank 0)")
+            if self.rank != 0:
+                self.coords.copy_(pack[1:1 + N * nd].reshape(N, nd))
+                self.lnp.copy_(pack[1 + N * nd:1 + N * nd + N])
+                self.naccept.copy_(pack[1 + N * nd + N:].to(torch.int32))
+            if self.broadcast_chain:
+                self._bcast(chain)
+                self._bcast(chain_lnp)
 
     def _timed(self, fn, k):
         """Seconds this rank needs for k steps of fn from the present state, which is restored."""

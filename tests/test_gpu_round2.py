@@ -47,16 +47,20 @@ K_SENS = 20.0
 _SENS = {}
 
 
-def _sensitivity(batch, walkers):
-    """(resp_sb, resp_lnp) of the reference binary for the given walker indices of a batch (all of them must be in the fixture)."""
+def _sensitivity(batch, walkers, missing_ok=False):
+    """(resp_sb, resp_lnp) of the reference binary for the given walker indices of a batch.  All of them must be in the fixture
+    unless missing_ok: a walker it does not hold (one the prior rejects, which only the flux call ever solves) gets response 0,
+    i.e. the plain tolerance."""
     if not _SENS:
         f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_sensitivity.npz"))
         _SENS.update({k: f[k] for k in f.files})
     w = _SENS[batch + "_walker"]
     walkers = np.asarray(walkers, dtype=np.int64)
-    pos = np.searchsorted(w, walkers)
-    assert len(w) and (pos < len(w)).all() and np.array_equal(w[pos], walkers), "maxiter walkers of %s missing from ref_sensitivity.npz" % batch
-    return _SENS[batch + "_resp_sb"][pos].astype(np.float64), _SENS[batch + "_resp_lnp"][pos].astype(np.float64)
+    pos = np.minimum(np.searchsorted(w, walkers), len(w) - 1)
+    have = w[pos] == walkers
+    assert len(w) and (missing_ok or have.all()), "maxiter walkers of %s missing from ref_sensitivity.npz" % batch
+    return (np.where(have, _SENS[batch + "_resp_sb"][pos], 0.0).astype(np.float64),
+            np.where(have, _SENS[batch + "_resp_lnp"][pos], 0.0).astype(np.float64))
 
 
 def _maxiter_ceiling(batch, walkers):
@@ -206,7 +210,7 @@ def test_full_width_parity_config5(eng, mol):
     st0.backrad(cfg["tbg"])
     W = cfg["walkers"]
     tol = 1e-4 * np.abs(rflux) + 1e-10 * (st0.arr("backi").max() * 10.0 ** W[:, 3] * 1e23)[:, None]      # (_flux_ok's)
-    resp_sb = _sensitivity("config5_65536", np.flatnonzero(mx))[0]
+    resp_sb = _sensitivity("config5_65536", np.flatnonzero(mx), missing_ok=True)[0]    # (mx: the flux call's status, no prior)
     assert frac_ok >= 0.999 and (ok[mx] | (d[mx] <= tol[mx] * (1.0 + K_SENS * resp_sb)[:, None])).all()
 
 
