@@ -5,7 +5,7 @@
 
 Row a6 of SURVEY.md section 8: readdata_ [radex.so@0x1cf90; called at emcee/pyradex/core.py:570,744; a bad file surfaces in
 the reference as an exception at construction, core.py:293-298, 738-739].  The first real co.dat a user brings will not be the
-two well-formed files the parser has been pinned on, so this writes ~60 small mutations of tests/golden/toy6.dat (truncations,
+two well-formed files the parser has been pinned on, so this writes 95 small mutations of tests/golden/toy6.dat (truncations,
 counts that disagree with the rows, indices outside the level list, negative rates, `d` / `D` / missing exponent letters, tabs,
 CRLF, values continued on the next record, a 70-level molecule, E_up <= E_low, ...) and runs the reference's own machine code on
 every one of them, each in a fresh process with a fresh image (a STOP ends the process).  Recorded per file:

@@ -40,9 +40,9 @@ def _rel(a, b):
 # (scripts/ref_sensitivity.py, container only) holds for every such walker of the batches below how far radex.so's own answer
 # moves when its exp / log are one ulp off -- in units of the flux tolerance (resp_sb) and as relative lnlike (resp_lnp).  A GPU
 # walker may deviate by  K_SENS x that response + north_star's 1e-4;  everywhere else the plain tolerance holds.  Measured over sixteen
-# draws of 131 072 prior-box walkers (49 800 at maxiter, profiles/r6_maxiter_vs_ref_sensitivity.txt): the GPU has 8 walkers beyond
+# draws of 131 072 prior-box walkers (49 947 at maxiter, profiles/r6_maxiter_vs_ref_sensitivity.txt): the GPU has 8 walkers beyond
 # the flux tolerance (worst 191 x, lnprob 1.2e-3) -- all 8 rank first to third among the ~3100 binary responses of their draw (the
-# binary itself moves 16 walkers beyond the tolerance, worst 29 x), and the smallest K that covers every walker is 6.6.
+# binary itself moves 13 walkers beyond the tolerance, worst 29 x), and the smallest K that covers every walker is 6.6.
 K_SENS = 20.0
 _SENS = {}
 
