@@ -181,3 +181,63 @@ def test_gpu_solves_on_every_accepted_corpus_file(ref):
         done.append(name)
         e.close()
     assert len(done) >= 25, done
+
+
+def test_reader_differential_fuzz(checker, tmp_path):
+    """600 seeded random mutations of toy6.dat (bytes replaced by the characters list-directed input cares about, bytes dropped or
+    inserted, records dropped / doubled / swapped, truncations): the product's reader under ASan + UBSan and the checker's reader
+    -- two independent restatements of the same Fortran READ sequence -- must take the same decision on every one of them and,
+    where they accept, hold the same tables.  No sanitizer report, no crash, no hang."""
+    rng = np.random.default_rng(20260605)
+    base = open(os.path.join(ROOT, "tests", "golden", "toy6.dat"), "rb").read()
+    alphabet = b" \t,-+.eEdD0123456789/*'\"!\r\n\x00x"
+    n_acc = n_rej = 0
+    for k in range(600):
+        b = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            op = int(rng.integers(0, 7))
+            pos = int(rng.integers(0, len(b)))
+            if op == 0:
+                b[pos] = alphabet[int(rng.integers(0, len(alphabet)))]
+            elif op == 1:
+                del b[pos]
+            elif op == 2:
+                b.insert(pos, alphabet[int(rng.integers(0, len(alphabet)))])
+            elif op == 3:
+                b = b[:pos]
+            else:
+                lines = bytes(b).split(b"\n")
+                i, j = int(rng.integers(0, len(lines))), int(rng.integers(0, len(lines)))
+                if op == 4:
+                    del lines[i]
+                elif op == 5:
+                    lines.insert(i, lines[j])
+                else:
+                    lines[i], lines[j] = lines[j], lines[i]
+                b = bytearray(b"\n".join(lines))
+            if not b:
+                break
+        path = str(tmp_path / ("m%03d.dat" % k))
+        with open(path, "wb") as f:
+            f.write(bytes(b))
+        r = subprocess.run([checker, path], capture_output=True, text=True, timeout=60)
+        assert r.returncode in (0, 3), (k, r.returncode, r.stderr[-1500:])
+        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (k, r.stderr[-1500:])
+        got = json.loads(r.stdout)
+        try:
+            m = O.Molecule(path)
+        except ValueError:
+            m = None
+        assert (m is not None) == (r.returncode == 0), (k, got.get("error"), bytes(b)[:80])
+        if m is None:
+            n_rej += 1
+            continue
+        n_acc += 1
+        assert (got["nlev"], got["nline"], got["npart"]) == (m.nlev, m.nline, m.npart), k
+        for key in ("eterm", "gstat", "aeinst", "spfreq", "xnu", "eup"):
+            assert np.array_equal(np.array(got[key]), getattr(m, key)), (k, key)
+        assert got["iupp"] == list(m.iupp) and got["ilow"] == list(m.ilow), k
+        for (pid, temps, lcu, lcl, coll), g in zip(m.partner_tables(), got["partners"]):
+            assert pid == g["id"] and list(lcu) == g["lcu"] and list(lcl) == g["lcl"], k
+            assert np.array_equal(temps, np.array(g["temps"])) and np.array_equal(coll.ravel(), np.array(g["coll"], dtype=np.float64)), k
+    assert n_acc > 60 and n_rej > 200, (n_acc, n_rej)
