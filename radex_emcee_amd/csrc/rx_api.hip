@@ -332,6 +332,14 @@ int validate_molecule(rx_handle *h)
             for (int t = 0; t < P.ntemp; ++t)
                 if (P.coll[(size_t)c * P.ntemp + t] < 0.0) { h->err = "negative collision rate"; return RX_E_IO; }
         }
+    // the kernels find the bracket T_i < T_kin <= T_i+1 of the reference's sequential search by COUNTING the grid points below T_kin:
+    // the same bracket for a grid that ascends (repeats allowed); a grid that descends never reaches the search (T_kin <= T_1 or
+    // T_kin >= T_ntemp always holds); any other order would give another bracket than the reference's
+    for (const Partner &P : m.parts) {
+        bool up = true, down = true;
+        for (int t = 0; t + 1 < P.ntemp; ++t) { up = up && P.temps[t] <= P.temps[t + 1]; down = down && P.temps[t] >= P.temps[t + 1]; }
+        if (!up && !down) { h->err = "collision temperatures are neither in ascending nor in descending order"; return RX_E_UNSUPP; }
+    }
     for (size_t a = 0; a < m.parts.size(); ++a)
         for (size_t b = a + 1; b < m.parts.size(); ++b)
             if (m.parts[a].id == m.parts[b].id) { h->err = "duplicate collision partner id"; return RX_E_UNSUPP; }

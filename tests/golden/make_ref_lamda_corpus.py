@@ -5,7 +5,7 @@
 
 Row a6 of SURVEY.md section 8: readdata_ [radex.so@0x1cf90; called at emcee/pyradex/core.py:570,744; a bad file surfaces in
 the reference as an exception at construction, core.py:293-298, 738-739].  The first real co.dat a user brings will not be the
-two well-formed files the parser has been pinned on, so this writes 95 small mutations of tests/golden/toy6.dat (truncations,
+two well-formed files the parser has been pinned on, so this writes 97 small mutations of tests/golden/toy6.dat (truncations,
 counts that disagree with the rows, indices outside the level list, negative rates, `d` / `D` / missing exponent letters, tabs,
 CRLF, values continued on the next record, a 70-level molecule, E_up <= E_low, ...) and runs the reference's own machine code on
 every one of them, each in a fresh process with a fresh image (a STOP ends the process).  Recorded per file:
@@ -120,6 +120,8 @@ def corpus():
         "ok_duplicate_rate_row": sub(T, col0 + 12, "   13     2     1   9.9e-11  9.9e-11  9.9e-11  9.9e-11"),
         "ok_upward_rate_listed": sub(T, col0 + 12, "   13     1     6   5.0e-13  9.0e-13  1.6e-12  2.8e-12"),
         "ok_temps_descending": sub(T, TEMPS, "  300.0  100.0   30.0   10.0"),
+        "ok_temps_shuffled": sub(T, TEMPS, "   10.0  300.0   30.0  100.0"),
+        "ok_temps_with_a_repeat": sub(T, TEMPS, "   10.0   30.0   30.0  300.0"),
         "ok_fewer_rate_rows_declared": sub(T, NCOLL, "11"),
         "ok_ladder41": big_molecule(41),
         "ok_ladder70": big_molecule(70),

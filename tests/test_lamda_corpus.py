@@ -1,6 +1,6 @@
 """Row a6 on ill-formed input: the LAMDA reader against what the REFERENCE BINARY's readdata_ does with the same files.
 
-tests/golden/lamda_corpus/ holds 95 small files (mutations of toy6.dat, a 41- and a 70-level ladder) and
+tests/golden/lamda_corpus/ holds 97 small files (mutations of toy6.dat, a 41- and a 70-level ladder) and
 tests/golden/ref_lamda_corpus.json what radex.so's own machine code made of each of them (make_ref_lamda_corpus.py: accepted ->
 the parsed tables and crate / ctot at two temperatures; STOP; an I/O condition libgfortran ends the run on; an input form the
 loader's shim does not implement) [/root/reference/emcee/pyradex/core.py:293-298, 570, 738-744: a bad file is an exception
@@ -42,6 +42,7 @@ UNSUPPORTED_BY_KERNELS = {
     "ok_lower_energy_upper_level_collision": "E_up <= E_low",
     "bad_rate_same_level": "E_up <= E_low",
     "ok_duplicate_partner_id": "duplicate collision partner id",
+    "ok_temps_shuffled": "neither in ascending nor in descending order",
     "bad_negative_rate": "negative collision rate",
     "bad_negative_rate_one_column": "negative collision rate",
 }
