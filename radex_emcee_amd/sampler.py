@@ -779,8 +779,8 @@ class DeviceEnsembleSampler:
 
     # --- "rank0": the ensemble on one GPU, one broadcast per call -----------------------------------------
     def _bcast(self, t):
-        if self.world == 1 or t is None:
-            return
+        if t is None or not self._sharded:
+            return                      # (a group of ONE rank still makes the call: the RCCL path of the one-rank GPU test)
         if t.is_cuda and self._dist.get_backend(self.group) == "gloo":     # (rehearsals: ranks that share one GPU)
             h = t.cpu()
             self._dist.broadcast(h, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)

@@ -154,3 +154,5 @@ def test_bench_collectives_over_rccl_with_a_one_rank_group():
         sh = d["sharded"][name]
         assert sh["multi_gpu_dataflow"]["same_final_state_as_one_gpu"] is True
         assert sh["multi_gpu_halfsteps_allgather"]["same_final_state_as_one_gpu"] is True
+        # schedule="auto" with a group of one rank: rank 0 alone, and the state broadcast is a real RCCL call on device buffers
+        assert sh["auto"]["chosen"] == "rank0" and sh["auto"]["same_final_state_as_one_gpu"] is True, sh["auto"]
