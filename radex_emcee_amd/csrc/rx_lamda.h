@@ -67,7 +67,7 @@ public:
         fresh_ = false;
         const char c = rec_.empty() ? ' ' : rec_[0];
         if (c == ' ') { v = 0; return true; }
-        if (c < '0' || c > '9') return fail(std::string("bad integer '") + c + "'");
+        if (c < '0' || c > '9') return fail("bad integer '" + shown(std::string(1, c)) + "'");
         v = c - '0';
         return true;
     }
@@ -111,7 +111,12 @@ private:
     size_t col_ = 0;
     bool fresh_ = true;
 
-    static std::string shown(const std::string &t) { return t.size() > 24 ? t.substr(0, 24) + "..." : t; }
+    // (a token as it goes into an error message: printable ASCII only -- the file may hold anything)
+    static std::string shown(const std::string &t) {
+        std::string o = t.size() > 24 ? t.substr(0, 24) + "..." : t;
+        for (char &c : o) if ((unsigned char)c < 0x20 || (unsigned char)c > 0x7e) c = '?';
+        return o;
+    }
     bool fail(const std::string &w) { if (why_.empty()) why_ = w; return false; }
     bool next_record() {
         rec_.clear();

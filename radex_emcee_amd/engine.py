@@ -57,7 +57,7 @@ class Engine:
         self._h = self._L.rx_create(self.molfile.encode(), METHODS[escapeProbGeom], float(deltav),
                                     int(device), err, 512)
         if not self._h:
-            raise EngineError("rx_create failed: " + err.value.decode())
+            raise EngineError("rx_create failed: " + err.value.decode("utf-8", "replace"))
         self.device = int(device)
         self.nlev = self._L.rx_nlev(self._h)
         self.nline = self._L.rx_nline(self._h)

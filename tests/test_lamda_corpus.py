@@ -133,6 +133,7 @@ def test_rx_create_rejects_what_the_binary_rejects(ref):
         err = C.create_string_buffer(512)
         h = L.rx_create(os.path.join(CORPUS, name + ".dat").encode(), 2, 1.0, 0, err, 512)
         msg = err.value.decode("latin-1")
+        assert all(0x20 <= ord(c) <= 0x7e for c in msg), (name, msg)      # (whatever the file holds, the message is printable)
         if h:
             L.rx_destroy(h)
         if not _expect_accept(name, rec):
@@ -141,6 +142,10 @@ def test_rx_create_rejects_what_the_binary_rejects(ref):
             assert not h and UNSUPPORTED_BY_KERNELS[name] in msg, (name, msg)
         else:
             assert h or "no usable HIP device" in msg, (name, msg)
+    # the Python front end: an EngineError with the library's message, never a decoding error
+    from radex_emcee_amd.engine import Engine, EngineError
+    with pytest.raises(EngineError, match="malformed LAMDA file"):
+        Engine(os.path.join(CORPUS, "bad_binary_garbage.dat"))
 
 
 @pytest.mark.gpu
