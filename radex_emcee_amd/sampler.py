@@ -792,10 +792,22 @@ class DeviceEnsembleSampler:
     def _unsharded(self, nsteps, chain, chain_lnp):
         """nsteps steps on THIS rank alone, with the schedule a sampler without a group uses."""
         if self.engine is not None and not self.time_solves:
-            self.engine.sampler_run_async_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed,
-                                                self.step_counter, nsteps, self.coords, self.lnp, self.naccept,
-                                                chain, chain_lnp, ens_src=self.ens_src)
-            self.engine.sampler_wait(self.coords.device)
+            from .engine import EngineError, RX_E_TIMEOUT
+            start = (self.coords.clone(), self.lnp.clone(), self.naccept.clone())
+            try:
+                self.engine.sampler_run_async_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed,
+                                                    self.step_counter, nsteps, self.coords, self.lnp, self.naccept,
+                                                    chain, chain_lnp, ens_src=self.ens_src)
+                self.engine.sampler_wait(self.coords.device)
+            except EngineError as exc:
+                if exc.rc != RX_E_TIMEOUT or not self.fallback:
+                    raise
+                # (as without a group: the dataflow kernel's own give-up is repeated per half-step from the state the call began with)
+                for dst, src in zip((self.coords, self.lnp, self.naccept), start):
+                    dst.copy_(src)
+                self.engine.sampler_run_torch(self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed, self.step_counter, nsteps,
+                                              self.coords, self.lnp, self.naccept, chain, chain_lnp, ens_src=self.ens_src,
+                                              time_solves=False)
         elif self.engine is not None:
             self.last_solve_ms = self.engine.sampler_run_torch(
                 self.nens, self.nwalkers, self.ndim // 4, self.a, self.seed, self.step_counter, nsteps,
