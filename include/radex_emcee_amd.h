@@ -167,7 +167,7 @@ int rx_set_waves_per_simd(rx_handle *h, int waves);
  * r6_small_population_gpu.txt): the iteration count of about 1 walker in 10^4 flips by one; lnprob of converged walkers moves by
  * up to 2e-6 relative; walkers that stop at maxiter (chaotic iterations) move by up to 1.2e-3 (9.8e-4 with it off); level
  * populations above 1e-6 by up to 5e-8 relative (1e-8 with it off).  Populations BELOW ~1e-11 differ from the reference's by
- * more than 1e-4 relative WITH OR WITHOUT it (same figures either way: the absolute deviation stays below 1e-14): that is the
+ * more than 1e-4 relative WITH OR WITHOUT it (same figures either way: below 1.2e-14 absolute for every population under 1e-6): that is the
  * rounding error of any double-precision solve of this system, the reference's own LINPACK solve included -- against the exact
  * solution of its own system it is off by 4e-4 at 1e-12, 5 % at 1e-14 and by factors below 1e-17
  * (profiles/r6_small_population_accuracy.txt) -- so T_ex and tau of lines between such levels, and fluxes under the

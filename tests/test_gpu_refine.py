@@ -127,7 +127,7 @@ def test_every_level_population_componentwise_with_the_refinement_on(co_path, mo
     term is what a double-precision solve of this system is worth (the reference's own LINPACK solution is off from the exact
     solution of its matrix by 4e-4 at a population of 1e-12, by 5 % at 1e-14: profiles/r6_small_population_accuracy.txt), and
     the device's deviation from the reference's numbers is the same with the refinement on and off
-    (profiles/r6_small_population_gpu.txt: largest absolute deviation 1.2e-14 either way).  T_ex / tau: lines whose two levels
+    (profiles/r6_small_population_gpu.txt: populations below 1e-6 deviate by at most 1.2e-14 absolute either way).  T_ex / tau: lines whose two levels
     both hold more than 1e-9 of the molecules."""
     e = Engine(co_path)
     rng = np.random.default_rng(2468)
