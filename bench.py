@@ -26,10 +26,12 @@ the schedule that actually ran and why.  The strong-scaling shapes of BASELINE c
 prior-box walkers; 2048 two-component walkers; 65536 walkers: ONE ensemble each, whatever N)
 are timed through the device-resident sampler ("sharded": {...}, walker-steps/s): first on rank 0's GPU
 alone (the one-GPU dataflow kernel -- the number every multi-GPU schedule has to beat), then across the N
-ranks with the peer-write dataflow schedule (opt-in; every rank's persistent kernel publishes into all replicas
+ranks with the peer-write dataflow schedule (every rank's persistent kernel publishes into all replicas
 over xGMI, no collective; the sampler first checks its first steps against the half-step schedule, bit for bit, on
-every rank) and with the half-step schedule north_star spells out (block evaluation per rank, ONE all_gather of
-log-probabilities per half-step), each with its speedup over the one-GPU number.  The 16
+every rank), with the half-step schedule north_star spells out (block evaluation per rank, ONE all_gather of
+log-probabilities per half-step), and as a sampler constructed WITHOUT naming a schedule runs it ("auto": rank 0 alone +
+one broadcast per call for ensembles in one GPU's latency regime, the fastest candidate by a timed probe otherwise),
+each with its speedup over the one-GPU number.  The 16
 independent ensembles of configs[2] are dealt out 16/N per rank as replicas (no collective).
 Rank 0 prints ONE JSON line.
 """
@@ -521,7 +523,7 @@ def main():
                                                 stt=st1 if rank == 0 else None)
                 if use_dist:
                     grp = dist.group.WORLD
-                    # (2) the same ensemble across the ranks, dataflow with peer writes: opt-in, and the sampler compares its first
+                    # (2) the same ensemble across the ranks, dataflow with peer writes: the sampler compares its first
                     # steps with the half-step schedule on every rank before it relies on the path (falls back by itself)
                     smp = DeviceEnsembleSampler(nwk, ndim, engine=eng, seed=2024, ens_src=ens_src, group=grp, schedule="dataflow")
                     d2, sha2 = timed_run(smp, c["walkers"], nst)
