@@ -133,5 +133,14 @@ int main()
     hipMemcpy(hD, dD, 2048, hipMemcpyDeviceToHost);
     double worst = 0; for (int i = 0; i < 256; ++i) worst = fmax(worst, fabs(hD[i] - ref[i]) / fabs(ref[i]));
     printf("layout A[l%%16][l/16], B[l/16][l%%16] -> D[(l/16)+4r][l%%16]: max rel dev from the host product %.1e\n", worst);
+    // What a right-looking blocked elimination of the 41 x 41 system (48-padded: 3 x 3 tiles of 16 x 16, panels of 4 columns) would
+    // need from the matrix unit alone: after panel k the tiles with rows and columns >= 4 k + 4 get one 16x16x4 update each.
+    int tiles = 0;
+    for (int k = 0; k < 12; ++k) { const int t0 = (4 * k + 4) / 16; tiles += (3 - t0) * (3 - t0); }
+    const double fma_now = 843 * 4.5;            // the FMAs of lu2d_solve (843 per solve, 4.5 cycles each for a lone wavefront: DESIGN.md section 5)
+    printf("blocked LU, trailing updates only: %d MFMAs = %.0f cycles (no vector instruction issues meanwhile); lu2d_solve spends %.0f of its 10 870\n"
+           "cycles in FMAs, the other ~7 000 in the 41 pivot searches / reciprocals / hand-overs a panel factorisation needs just the same, and LU\n"
+           "adds two triangular solves (2 x 41 dependent steps) that Gauss-Jordan does not have: best case %.0f + 7 000 + solves > 10 870 x 0.75.\n",
+           tiles, tiles * ind, fma_now, tiles * ind);
     return 0;
 }
