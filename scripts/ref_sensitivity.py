@@ -17,7 +17,8 @@ maxiter, matrix_ is driven as emcee/pyradex/core.py:903-920 drives it, once unpe
 
 Batches: the sixteen 131 072-walker prior-box draws of scripts/big_parity_seeds.py (profiles/r5_big_parity_seeds.txt), and the
 batches of the GPU tests whose maxiter tier used to have the flat ceiling MAXITER_CEIL = 3e-3 (tests/test_gpu_round2.py):
-config2(65536, seed 5678), config3(512), config4(4096) with its prior-box half, config4(2048).
+config2(65536, seed 5678), config3(512), config4(4096) with its prior-box half, config4(2048); and EVERY walker of the bench
+headline (config2(1024, seed 1234): `headline_1024_all`, with the iteration counts and whether a perturbation moved them).
 The oracle only CHOOSES (which walkers to run: its iteration counts equal the binary's, tests/test_oracle_ref_configs.py -- and every
 chosen walker is checked to reach maxiter in the binary too) and supplies the batches' synthetic data (flux at the truth).
 """
@@ -162,7 +163,7 @@ def job(args):
     w, p, tbg, jidx, flux, esig = args
     ncomp = len(p) // 4
     base, pert = [], [[] for _ in range(NPERT)]
-    nit = 0
+    nit, nit_moved = 0, False
     for c in range(ncomp):
         q = p[4 * c:4 * c + 4]
         setup(q[0], q[1], q[2], tbg)
@@ -170,7 +171,9 @@ def job(args):
         nit = max(nit, it)
         base.append((sb, bmax, q[3]))
         for k in range(NPERT):
-            pert[k].append(iterate(1000 * k + 17 + c)[1])
+            itk, sbk, _ = iterate(1000 * k + 17 + c)
+            nit_moved = nit_moved or itk != it
+            pert[k].append(sbk)
     resp_sb, resp_lnp = 0.0, 0.0
     m0 = sum(sb[jidx] * 10.0 ** s * 1e23 for sb, _, s in base)
     for k in range(NPERT):
@@ -184,7 +187,7 @@ def job(args):
             l0 = lnlike(m0, flux, esig)
             dl = abs(lnlike(mk, flux, esig) - l0) / max(abs(l0), 1.0)
         resp_lnp = max(resp_lnp, float(dl) if np.isfinite(dl) else 0.0)
-    return w, nit, resp_sb, resp_lnp
+    return w, nit, resp_sb, resp_lnp, float(nit_moved)
 
 
 def batches():
@@ -205,6 +208,12 @@ def batches():
             src, tf = truth(cfg)
             return cfg["walkers"], [src], np.zeros(131072, dtype=np.int32), [(cfg["tbg"], np.asarray(cfg["Jup"]) - 1, tf, 0.1 * tf)]
         out["big_%d" % seed] = mk
+
+    def headline():
+        cfg = workloads.config2(1024, seed=1234)
+        src, tf = truth(cfg)
+        return cfg["walkers"], [src], np.zeros(1024, dtype=np.int32), [(cfg["tbg"], np.asarray(cfg["Jup"]) - 1, tf, 0.1 * tf)]
+    out["headline_1024_all"] = headline                    # (EVERY walker of the bench headline, converged ones included)
 
     def c5():
         cfg = workloads.config2(65536, seed=5678)
@@ -255,7 +264,7 @@ def main():
             for k, src in enumerate(srcs):                 # the oracle CHOOSES: status 1 = some component stopped at maxiter
                 m = sidx == k
                 st[m] = O.lnprob_batch(mol, src, W[m], nthreads=a.procs)[1]
-            idx = np.flatnonzero(st == 1)
+            idx = np.flatnonzero(st == 1) if not name.endswith("_all") else np.flatnonzero(st != 3)
             if a.limit:
                 idx = idx[:a.limit]
             jobs = [(int(w), W[w], data[sidx[w]][0], data[sidx[w]][1], data[sidx[w]][2], data[sidx[w]][3]) for w in idx]
@@ -265,16 +274,25 @@ def main():
                 if (k + 1) % 500 == 0:
                     print("  %s: %d / %d walkers, %.0f s" % (name, k + 1, len(jobs), time.time() - t0), flush=True)
             rows.sort()
-            r = np.array(rows, dtype=np.float64).reshape(-1, 4)
-            assert np.all(r[:, 1] >= 200), "%s: a chosen walker does not reach maxiter in the binary" % name
+            r = np.array(rows, dtype=np.float64).reshape(-1, 5)
+            if name.endswith("_all"):
+                out[name + "_niter"] = r[:, 1].astype(np.int32)
+                out[name + "_niter_moved"] = r[:, 4].astype(np.int8)
+                conv = r[:, 1] < 200
+                print("%s: %d walkers, %d converge: their 1-ulp response max %.2e of the flux tolerance, relative |d lnlike| max %.2e; "
+                      "iteration counts moved by the perturbation: %d" % (name, len(r), int(conv.sum()), r[conv, 2].max(), r[conv, 3].max(),
+                                                                           int(r[:, 4].sum())), flush=True)
+            else:
+                assert np.all(r[:, 1] >= 200), "%s: a chosen walker does not reach maxiter in the binary" % name
             out[name + "_walker"] = r[:, 0].astype(np.int32)
             out[name + "_resp_sb"] = r[:, 2].astype(np.float32)
             out[name + "_resp_lnp"] = r[:, 3].astype(np.float32)
             q = r[:, 2]
-            print("%s: %d maxiter walkers; 1-ulp response in units of the flux tolerance: median %.2e, 99th pct %.2e, max %.2e, "
-                  "above 1: %d; relative |d lnlike| max %.2e  (%.0f s)"
-                  % (name, len(q), np.median(q), np.percentile(q, 99), q.max(), int((q > 1).sum()), r[:, 3].max(), time.time() - t0),
-                  flush=True)
+            if not name.endswith("_all"):
+                print("%s: %d maxiter walkers; 1-ulp response in units of the flux tolerance: median %.2e, 99th pct %.2e, max %.2e, "
+                      "above 1: %d; relative |d lnlike| max %.2e  (%.0f s)"
+                      % (name, len(q), np.median(q), np.percentile(q, 99), q.max(), int((q > 1).sum()), r[:, 3].max(), time.time() - t0),
+                      flush=True)
             save_deterministic(OUT, out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

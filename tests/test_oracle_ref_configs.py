@@ -74,3 +74,10 @@ def test_sensitivity_fixture_names_the_maxiter_walkers_of_the_test_batches(mol, 
     assert len(resp) == 49947
     assert int((resp > 1.0).sum()) == 13 and 28.0 < resp.max() < 29.5                # the binary itself: 13 walkers beyond the tolerance, worst 29 x
     assert np.median(resp) < 1e-7
+    # every walker of the bench headline, converged ones included: a libm that differs by one ulp moves no iteration count (they
+    # are the binary's own of ref_configs.npz) and the converged walkers by less than 1e-3 of the flux tolerance
+    ref = np.load(os.path.join(golden_dir, "ref_configs.npz"))
+    assert np.array_equal(f["headline_1024_all_walker"], np.arange(1024)) and np.array_equal(f["headline_1024_all_niter"], ref["c2_niter"])
+    assert int(f["headline_1024_all_niter_moved"].sum()) == 0
+    conv = f["headline_1024_all_niter"] < 200
+    assert conv.sum() >= 1000 and f["headline_1024_all_resp_sb"][conv].max() < 1e-3 and f["headline_1024_all_resp_lnp"][conv].max() < 1e-10
